@@ -1,0 +1,166 @@
+/* pathtracer_amd -- C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * The reference renderer has no plugin interface; its boundary to the GPU is the
+ * ray-tracing descriptor set plus one vkCmdTraceRaysKHR per frame
+ * (PathTracer/src/RayTracingLayer.cpp:201-284, bindings 0-11 at :248-263).
+ * Every entry point below replaces one piece of that boundary and cites it.
+ * Plain pointers and sizes only; the caller owns every host array and the
+ * library copies what it needs before returning.  All functions return 0 on
+ * success or a PT_ERR_* code; pt_last_error() gives the text.  A context is not
+ * thread safe; use one context per GPU.
+ */
+#ifndef PATHTRACER_AMD_H
+#define PATHTRACER_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_ERR_INVALID 1      /* bad argument / call order */
+#define PT_ERR_HIP 2          /* a HIP runtime call failed */
+#define PT_ERR_NO_DEVICE 3    /* no gfx950 device, or ordinal out of range */
+#define PT_ERR_BVH_DEPTH 4    /* built hierarchy deeper than the traversal stack */
+#define PT_ERR_TOO_LARGE 5    /* size beyond a documented limit */
+
+/* binding 9: sampler2D u_Textures[] (ClosestHit.glsl:15).  RGBA8 UNORM texels,
+ * row 0 first; sampled bilinear / repeat / level 0. */
+typedef struct pt_texture_desc {
+    uint32_t width, height;
+    uint32_t flags;            /* reserved, must be 0 */
+    uint32_t pad_;
+    const uint8_t* rgba8;
+} pt_texture_desc;
+
+/* The scene tables the absent engine's Mesh / AccelerationStructure hand to the
+ * shaders (RayTracingLayer.cpp:207,227-260):
+ *   binding 4  vertices: 12 floats each = pos3 uv2 nrm3 tan4 (ClosestHit.glsl:56-81)
+ *   binding 5  indices:  uint32
+ *   binding 6  submeshes: 4 uint32 each = bufferIndex(0), vertexOffset, indexOffset,
+ *              materialIndex (ClosestHit.glsl:147-150); one TLAS instance per submesh
+ *   binding 8  materials: 22 words each (ClosestHit.glsl:113-142)
+ *   binding 10 env cube: 6 faces (+X,-X,+Y,-Y,+Z,-Z) of face*face RGBA32F, or NULL
+ *              for a constant white sky
+ * plus what the driver keeps inside the TLAS: each submesh's index count and its
+ * object-to-world transform (3 rows of 4 floats), i.e.
+ * AccelerationStructureSpecification{Mesh, Transform} (RayTracingLayer.cpp:342-348)
+ * already multiplied with the submesh's WorldTransform. */
+typedef struct pt_scene_desc {
+    const float* vertices;
+    const uint32_t* indices;
+    const uint32_t* submeshes;
+    const uint32_t* submesh_index_counts;
+    const float* submesh_xforms;
+    const float* materials;
+    const pt_texture_desc* textures;
+    const float* env_rgba;
+    uint32_t num_vertices, num_indices, num_submeshes, num_materials, num_textures, env_face_size;
+} pt_scene_desc;
+
+/* Constants the reference hard-codes in RayGen.glsl; defaults = reference values. */
+typedef struct pt_params {
+    uint32_t spp_per_frame;    /* RayGen.glsl:319  SAMPLE_COUNT = 5 */
+    uint32_t max_bounces;      /* RayGen.glsl:111  MAX_BOUNCES = 20 */
+    uint32_t rr_depth;         /* RayGen.glsl:163-173 Russian roulette from this bounce on; 0 = off (reference) */
+    float sky_scale;           /* RayGen.glsl:132  10.0 */
+    float eps;                 /* RayGen.glsl:159  0.0003 */
+    float tmin;                /* RayGen.glsl:341  0.00001 */
+    float tmax;                /* RayGen.glsl:342  1e27 */
+} pt_params;
+
+typedef struct pt_accel_stats {
+    uint32_t num_triangles;
+    uint32_t num_nodes;        /* 4-wide nodes, 128 bytes each */
+    uint32_t max_depth;        /* levels of 4-wide nodes */
+    uint32_t num_leaves;
+    float build_ms;            /* device time of the build kernels */
+    float sah_cost;            /* surface-area-heuristic cost of the built hierarchy */
+} pt_accel_stats;
+
+/* per-kernel device time of the last pt_trace (HIP events on the context's stream) */
+typedef struct pt_trace_timing {
+    float total_ms, raygen_ms, extend_ms, shade_ms;
+    uint32_t extend_launches, shade_launches;
+    uint64_t rays;             /* ray segments traced by that call */
+} pt_trace_timing;
+
+typedef struct pt_ctx pt_ctx;
+
+/* Application::GetVulkanDevice() (RayTracingLayer.cpp:18): picks the GPU, creates the stream. */
+int pt_create(int device_ordinal, pt_ctx** out);
+void pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(pt_ctx* ctx);   /* ctx may be NULL: last error of pt_create */
+void pt_default_params(pt_params* out);
+
+/* Mesh vertex/index buffers, submesh table, material buffer, textures, radiance map:
+ * descriptor writes for bindings 4,5,6,8,9,10 (RayTracingLayer.cpp:227-263). */
+int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* scene);
+/* CreateAccelerationStructure() (RayTracingLayer.cpp:342-348): GPU build of the hierarchy
+ * that replaces the driver's BLAS/TLAS (binding 0).  flags: PT_BUILD_* below. */
+#define PT_BUILD_DEFAULT 0u
+#define PT_BUILD_LBVH 1u       /* Morton-order hierarchy only (no agglomerative refinement) */
+int pt_build_accel(pt_ctx* ctx, uint32_t flags, pt_accel_stats* stats);
+/* AccelerationStructure::UpdateMaterialData() (RayTracingLayer.cpp:621). */
+int pt_update_materials(pt_ctx* ctx, const float* materials, uint32_t num_materials);
+/* Image::Resize of m_Image and m_AccumulationImage (RayTracingLayer.cpp:392-393). */
+int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height);
+/* Optional: render into caller-owned device buffers (width*height*4 floats each)
+ * instead of the context's own images (bindings 1 and 2), e.g. torch tensors that a
+ * collective then reduces.  Pass NULL to go back to the context's own buffers. */
+int pt_bind_images(pt_ctx* ctx, void* device_image, void* device_accum);
+/* CameraBuffer upload, binding 3 (RayTracingLayer.h:17-24, RayTracingLayer.cpp:403-411):
+ * ViewProjection, InverseViewProjection, View, InverseView, InverseProjection,
+ * column-major (glm).  Only the last two are read by the shaders. */
+int pt_set_camera(pt_ctx* ctx, const float* five_mat4);
+int pt_set_params(pt_ctx* ctx, const pt_params* params);
+/* vkCmdTraceRaysKHR(width, height, 1) with SceneBuffer.FrameIndex = frame_index, binding 7
+ * (RayTracingLayer.cpp:274-283, RayGen.glsl:312-373).  Asynchronous on the context's
+ * stream.  The caller sequences frame_index (1-based; 1 clears the accumulation image). */
+int pt_trace(pt_ctx* ctx, uint32_t frame_index);
+/* waits for the stream (the reference's Submit + FlushCommandBuffer, RayTracingLayer.cpp:317,424) */
+int pt_sync(pt_ctx* ctx);
+/* o_Image / o_AccumulationImage read-back and restore (bindings 1 and 2); width*height*4 floats. */
+int pt_read_image(pt_ctx* ctx, float* rgba);
+int pt_read_accum(pt_ctx* ctx, float* rgba);
+int pt_write_accum(pt_ctx* ctx, const float* rgba);
+/* o_Image = accum.rgb / accum.a for every pixel (RayGen.glsl:367-372), for an accumulation
+ * image that was merged from several GPUs. */
+int pt_resolve(pt_ctx* ctx);
+/* (gl_InstanceCustomIndexEXT, gl_PrimitiveID) of the first sample's primary ray of the last
+ * frame, per pixel; 0xFFFFFFFF twice for a miss.  width*height*2 words. */
+int pt_read_primary_ids(pt_ctx* ctx, uint32_t* submesh_prim_pairs);
+/* number of traceRayEXT-equivalents issued since the context was created */
+int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
+/* on: every kernel launch of later pt_trace calls is bracketed by HIP events on the
+ * context's stream; pt_last_trace_timing then reports the last frame's per-kernel time */
+int pt_set_profiling(pt_ctx* ctx, int on);
+int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out);
+/* the HIP stream pt_trace launches on (hipStream_t as void*) */
+void* pt_stream(pt_ctx* ctx);
+/* device pointers of the images currently rendered into */
+void* pt_device_image(pt_ctx* ctx);
+void* pt_device_accum(pt_ctx* ctx);
+
+/* ---- inspection hooks used by the parity tests ------------------------------------- */
+/* closest hit of caller-supplied rays: rays = n*8 floats (o.xyz, tmin, d.xyz, tmax);
+ * hits = n*5 words: t,u,v (float bits), submesh, prim; miss = (tmax,0,0,~0,~0).
+ * counters (may be NULL) = 2 uint64: hierarchy nodes visited, triangles tested. */
+int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
+/* the deterministic sin/cos/log/exp/pow used by the kernels: fn 0 sin,1 cos,2 log,3 exp,4 pow */
+int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n);
+/* DisneySample / DisneyEval (Disney.glsl:150-359) for n independent inputs.
+ * surf = n*17 floats: albedo3 metallic roughness subsurface specularTint sheen sheenTint
+ * clearcoat clearcoatRoughness specTrans ior ax ay eta anisotropic; V, N, L = n*3;
+ * seeds = n (updated in place); f = n*3; pdf = n. */
+int pt_debug_disney_sample(pt_ctx* ctx, uint32_t n, const float* surf, const float* V, const float* N,
+                           uint32_t* seeds, float* f, float* L, float* pdf);
+int pt_debug_disney_eval(pt_ctx* ctx, uint32_t n, const float* surf, const float* V, const float* N,
+                         const float* L, float* f, float* pdf);
+/* copies the built hierarchy to the host: nodes = num_nodes*32 words, tris = num_triangles*12 words */
+int pt_debug_read_bvh(pt_ctx* ctx, uint32_t* nodes, uint32_t* tris);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

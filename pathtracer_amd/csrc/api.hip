@@ -1,0 +1,445 @@
+// C ABI of the backend (declared in include/pathtracer_amd.h): context life cycle, uploads of the
+// reference's descriptor-set contents (PathTracer/src/RayTracingLayer.cpp:248-263), image management
+// and read-back.  No exception crosses the boundary; every entry point returns a status code.
+#include "pt_context.h"
+#include <cstring>
+#include <new>
+
+namespace ptd {
+
+static thread_local std::string g_create_error;
+
+int set_error(pt_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+template <class T>
+static hipError_t dev_free(T*& p)
+{
+    hipError_t e = hipSuccess;
+    if (p) e = hipFree(p);
+    p = nullptr;
+    return e;
+}
+
+static void free_scene(pt_ctx* c)
+{
+    (void)dev_free(c->d_vertices); (void)dev_free(c->d_indices); (void)dev_free(c->d_submeshes);
+    (void)dev_free(c->d_xforms); (void)dev_free(c->d_materials); (void)dev_free(c->d_tex_pool);
+    (void)dev_free(c->d_tex_table); (void)dev_free(c->d_env); (void)dev_free(c->d_sub_tri_offset);
+    (void)dev_free(c->d_nodes); (void)dev_free(c->d_tris);
+    c->scene_loaded = false;
+    c->accel_built = false;
+}
+
+static void free_images(pt_ctx* c)
+{
+    (void)dev_free(c->d_image_own); (void)dev_free(c->d_accum_own); (void)dev_free(c->d_primary);
+    (void)dev_free(c->d_rayO[0]); (void)dev_free(c->d_rayO[1]); (void)dev_free(c->d_rayD[0]); (void)dev_free(c->d_rayD[1]);
+    (void)dev_free(c->d_hits); (void)dev_free(c->d_stA); (void)dev_free(c->d_stB); (void)dev_free(c->d_stC);
+    c->d_image = c->d_accum = nullptr;
+    c->width = c->height = 0;
+}
+
+template <class T>
+static int upload(pt_ctx* ctx, T*& dst, const T* src, size_t n)
+{
+    PT_HIP(ctx, hipMalloc((void**)&dst, (n ? n : 1) * sizeof(T)));
+    if (n) PT_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return PT_OK;
+}
+
+static int finish_timing(pt_ctx* ctx)
+{
+    if (!ctx->timing_pending) return PT_OK;
+    ctx->timing_pending = false;
+    pt_trace_timing t{};
+    uint32_t R = ctx->timing_rounds;
+    std::vector<hipEvent_t>& ev = ctx->events;
+    float ms = 0.0f;
+    PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
+    t.raygen_ms = ms;
+    // device-side queue sizes tell which rounds had work
+    std::vector<uint32_t> counts(R + 1);
+    PT_HIP(ctx, hipMemcpy(counts.data(), ctx->d_counts, (R + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < R; r++) {
+        float e = 0.0f, s = 0.0f;
+        PT_HIP(ctx, hipEventElapsedTime(&e, ev[1 + 2 * r], ev[2 + 2 * r]));
+        PT_HIP(ctx, hipEventElapsedTime(&s, ev[2 + 2 * r], ev[3 + 2 * r]));
+        if (counts[r] > 0) {
+            t.extend_ms += e; t.shade_ms += s;
+            t.extend_launches++; t.shade_launches++;
+        }
+        t.rays += counts[r];
+    }
+    PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[2 + 2 * R]));
+    t.total_ms = ms;
+    ctx->timing = t;
+    return PT_OK;
+}
+
+} // namespace ptd
+
+using namespace ptd;
+
+extern "C" {
+
+int pt_create(int device_ordinal, pt_ctx** out)
+{
+    if (!out) return set_error(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return set_error(nullptr, PT_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device_ordinal < 0 || device_ordinal >= count) return set_error(nullptr, PT_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return set_error(nullptr, PT_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return set_error(nullptr, PT_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+    if (hipSetDevice(device_ordinal) != hipSuccess) return set_error(nullptr, PT_ERR_HIP, "hipSetDevice failed");
+    pt_ctx* ctx = new (std::nothrow) pt_ctx();
+    if (!ctx) return set_error(nullptr, PT_ERR_INVALID, "out of host memory");
+    ctx->device = device_ordinal;
+    ctx->num_cus = prop.multiProcessorCount;
+    pt_default_params(&ctx->params);
+    hipError_t es = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e1 = hipMalloc((void**)&ctx->d_total_rays, 8);
+    hipError_t e2 = hipMalloc((void**)&ctx->d_stats, 16);
+    if (es != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) { pt_destroy(ctx); return set_error(nullptr, PT_ERR_HIP, "context allocation failed"); }
+    (void)hipMemset(ctx->d_total_rays, 0, 8);
+    (void)hipMemset(ctx->d_stats, 0, 16);
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    free_images(ctx);
+    (void)dev_free(ctx->d_counts);
+    (void)dev_free(ctx->d_total_rays);
+    (void)dev_free(ctx->d_stats);
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* pt_last_error(pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+void pt_default_params(pt_params* p)
+{
+    p->spp_per_frame = 5;
+    p->max_bounces = 20;
+    p->rr_depth = 0;
+    p->sky_scale = 10.0f;
+    p->eps = 0.0003f;
+    p->tmin = 0.00001f;
+    p->tmax = 1e27f;
+}
+
+int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* s)
+{
+    if (!ctx || !s) return PT_ERR_INVALID;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!s->vertices || !s->indices || !s->submeshes || !s->submesh_index_counts || !s->submesh_xforms || !s->materials)
+        if (s->num_submeshes) return set_error(ctx, PT_ERR_INVALID, "pt_scene_upload: a required table is NULL");
+    // validate every index the kernels will follow, so that no launch can read out of bounds
+    std::vector<uint32_t> tri_off(s->num_submeshes + 1, 0);
+    for (uint32_t i = 0; i < s->num_submeshes; i++) {
+        const uint32_t* sm = s->submeshes + i * 4;
+        uint32_t cnt = s->submesh_index_counts[i];
+        if (sm[0] != 0) return set_error(ctx, PT_ERR_INVALID, "submesh bufferIndex must be 0 (one vertex and one index buffer)");
+        if (cnt % 3) return set_error(ctx, PT_ERR_INVALID, "submesh index count is not a multiple of 3");
+        if ((uint64_t)sm[2] + cnt > s->num_indices) return set_error(ctx, PT_ERR_INVALID, "submesh index range exceeds the index buffer");
+        if (sm[3] >= s->num_materials) return set_error(ctx, PT_ERR_INVALID, "submesh material index out of range");
+        for (uint32_t k = 0; k < cnt; k++)
+            if ((uint64_t)s->indices[sm[2] + k] + sm[1] >= s->num_vertices)
+                return set_error(ctx, PT_ERR_INVALID, "vertex index out of range in submesh " + std::to_string(i));
+        uint64_t total = (uint64_t)tri_off[i] + cnt / 3;
+        if (total > 0x0FFFFFFFull) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^28-1 triangles");
+        tri_off[i + 1] = (uint32_t)total;
+    }
+    for (uint32_t m = 0; m < s->num_materials; m++) {
+        for (int k = 10; k <= 12; k++) {
+            int32_t idx;
+            memcpy(&idx, &s->materials[(size_t)m * 22 + k], 4);
+            if (idx != -1 && (idx < 0 || (uint32_t)idx >= s->num_textures))
+                return set_error(ctx, PT_ERR_INVALID, "material " + std::to_string(m) + " names a texture that was not supplied");
+        }
+    }
+    for (uint32_t t = 0; t < s->num_textures; t++)
+        if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 || s->textures[t].flags != 0)
+            return set_error(ctx, PT_ERR_INVALID, "texture " + std::to_string(t) + " is empty or has unknown flags");
+
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    int rc;
+    if ((rc = upload(ctx, ctx->d_vertices, s->vertices, (size_t)s->num_vertices * 12))) return rc;
+    if ((rc = upload(ctx, ctx->d_indices, s->indices, s->num_indices))) return rc;
+    if ((rc = upload(ctx, ctx->d_submeshes, s->submeshes, (size_t)s->num_submeshes * 4))) return rc;
+    if ((rc = upload(ctx, ctx->d_xforms, s->submesh_xforms, (size_t)s->num_submeshes * 12))) return rc;
+    if ((rc = upload(ctx, ctx->d_materials, s->materials, (size_t)s->num_materials * 22))) return rc;
+    if ((rc = upload(ctx, ctx->d_sub_tri_offset, tri_off.data(), tri_off.size()))) return rc;
+    // textures: one pool of texels + a table (texel offset, width, height, flags)
+    std::vector<uint32_t> table((size_t)s->num_textures * 4 + 4, 0);
+    size_t texels = 0;
+    for (uint32_t t = 0; t < s->num_textures; t++) {
+        table[t * 4 + 0] = (uint32_t)texels;
+        table[t * 4 + 1] = s->textures[t].width;
+        table[t * 4 + 2] = s->textures[t].height;
+        table[t * 4 + 3] = s->textures[t].flags;
+        texels += (size_t)s->textures[t].width * s->textures[t].height;
+        if (texels > 0xFFFFFFFFull) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^32 texels");
+    }
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_tex_pool, (texels ? texels : 1) * 4));
+    for (uint32_t t = 0; t < s->num_textures; t++)
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_tex_pool + (size_t)table[t * 4] * 4, s->textures[t].rgba8,
+                                   (size_t)s->textures[t].width * s->textures[t].height * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload(ctx, ctx->d_tex_table, table.data(), table.size()))) return rc;
+    if (s->env_rgba && s->env_face_size) {
+        ctx->env_n = s->env_face_size;
+        if ((rc = upload(ctx, ctx->d_env, s->env_rgba, (size_t)6 * ctx->env_n * ctx->env_n * 4))) return rc;
+    } else {
+        // the reference's HDR sky is not in its repository: constant white radiance, one texel per face
+        float white[24];
+        for (float& w : white) w = 1.0f;
+        ctx->env_n = 1;
+        if ((rc = upload(ctx, ctx->d_env, (const float*)white, 24))) return rc;
+    }
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host arrays may go away after return
+    ctx->num_vertices = s->num_vertices; ctx->num_indices = s->num_indices; ctx->num_submeshes = s->num_submeshes;
+    ctx->num_materials = s->num_materials; ctx->num_textures = s->num_textures;
+    ctx->num_tris = tri_off[s->num_submeshes];
+    ctx->scene_loaded = true;
+    return PT_OK;
+}
+
+int pt_build_accel(pt_ctx* ctx, uint32_t flags, pt_accel_stats* stats)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->scene_loaded) return set_error(ctx, PT_ERR_INVALID, "pt_build_accel: no scene uploaded");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = build_accel(ctx, flags);
+    if (stats) *stats = ctx->accel_stats;
+    return rc;
+}
+
+int pt_update_materials(pt_ctx* ctx, const float* materials, uint32_t num_materials)
+{
+    if (!ctx || !materials) return PT_ERR_INVALID;
+    if (!ctx->scene_loaded || num_materials != ctx->num_materials)
+        return set_error(ctx, PT_ERR_INVALID, "pt_update_materials: material count differs from the uploaded scene");
+    for (uint32_t m = 0; m < num_materials; m++)
+        for (int k = 10; k <= 12; k++) {
+            int32_t idx;
+            memcpy(&idx, &materials[(size_t)m * 22 + k], 4);
+            if (idx != -1 && (idx < 0 || (uint32_t)idx >= ctx->num_textures))
+                return set_error(ctx, PT_ERR_INVALID, "material names a texture that was not supplied");
+        }
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_materials, materials, (size_t)num_materials * 88, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (width == 0 || height == 0) return set_error(ctx, PT_ERR_INVALID, "pt_resize: empty image");
+    if ((uint64_t)width * height > (1ull << 28)) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_resize: more than 2^28 pixels");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_images(ctx);
+    size_t n = (size_t)width * height;
+    size_t slots = (size_t)((width + 7) / 8) * ((height + 7) / 8) * 64;
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_image_own, n * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_accum_own, n * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_primary, n * 8));
+    for (int i = 0; i < 2; i++) {
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_rayO[i], slots * 16));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_rayD[i], slots * 16));
+    }
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_hits, slots * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stA, n * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stB, n * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stC, n * 16));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_image_own, 0, n * 16, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_accum_own, 0, n * 16, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, n * 8, ctx->stream));
+    ctx->d_image = ctx->d_image_own;
+    ctx->d_accum = ctx->d_accum_own;
+    ctx->width = width;
+    ctx->height = height;
+    return PT_OK;
+}
+
+int pt_bind_images(pt_ctx* ctx, void* device_image, void* device_accum)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "pt_bind_images: call pt_resize first");
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->d_image = device_image ? (float*)device_image : ctx->d_image_own;
+    ctx->d_accum = device_accum ? (float*)device_accum : ctx->d_accum_own;
+    return PT_OK;
+}
+
+int pt_set_camera(pt_ctx* ctx, const float* m)
+{
+    if (!ctx || !m) return PT_ERR_INVALID;
+    memcpy(ctx->camera, m, sizeof(float) * 80);
+    ctx->camera_set = true;
+    return PT_OK;
+}
+
+int pt_set_params(pt_ctx* ctx, const pt_params* p)
+{
+    if (!ctx || !p) return PT_ERR_INVALID;
+    if (p->spp_per_frame == 0 || p->max_bounces == 0) return set_error(ctx, PT_ERR_INVALID, "spp_per_frame and max_bounces must be >= 1");
+    if (p->spp_per_frame > 0xFFFFu || p->max_bounces > 0xFFFFu || (uint64_t)p->spp_per_frame * p->max_bounces > 65536ull)
+        return set_error(ctx, PT_ERR_TOO_LARGE, "spp_per_frame * max_bounces must not exceed 65536");
+    ctx->params = *p;
+    return PT_OK;
+}
+
+int pt_set_profiling(pt_ctx* ctx, int on)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    ctx->profiling = on != 0;
+    return PT_OK;
+}
+
+int pt_trace(pt_ctx* ctx, uint32_t frame_index)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->scene_loaded || !ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_trace: scene or hierarchy missing");
+    if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "pt_trace: call pt_resize first");
+    if (!ctx->camera_set) return set_error(ctx, PT_ERR_INVALID, "pt_trace: call pt_set_camera first");
+    if (frame_index == 0) return set_error(ctx, PT_ERR_INVALID, "pt_trace: frame_index is 1-based");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t rounds = ctx->params.spp_per_frame * ctx->params.max_bounces;
+    if (rounds + 1 > ctx->counts_cap) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)dev_free(ctx->d_counts);
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (rounds + 1) * sizeof(uint32_t)));
+        ctx->counts_cap = rounds + 1;
+    }
+    if (ctx->timing_pending) {   // a profiled frame is still in flight: collect it before its events are reused
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = finish_timing(ctx);
+        if (rc) return rc;
+    }
+    return launch_trace(ctx, frame_index);
+}
+
+int pt_sync(pt_ctx* ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return finish_timing(ctx);
+}
+
+static int read_back(pt_ctx* ctx, void* host, const void* dev, size_t bytes)
+{
+    if (!host) return PT_ERR_INVALID;
+    if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "no image: call pt_resize first");
+    PT_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return finish_timing(ctx);
+}
+
+int pt_read_image(pt_ctx* ctx, float* rgba) { return ctx ? read_back(ctx, rgba, ctx->d_image, (size_t)ctx->width * ctx->height * 16) : PT_ERR_INVALID; }
+int pt_read_accum(pt_ctx* ctx, float* rgba) { return ctx ? read_back(ctx, rgba, ctx->d_accum, (size_t)ctx->width * ctx->height * 16) : PT_ERR_INVALID; }
+int pt_read_primary_ids(pt_ctx* ctx, uint32_t* ids) { return ctx ? read_back(ctx, ids, ctx->d_primary, (size_t)ctx->width * ctx->height * 8) : PT_ERR_INVALID; }
+
+int pt_write_accum(pt_ctx* ctx, const float* rgba)
+{
+    if (!ctx || !rgba) return PT_ERR_INVALID;
+    if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "no image: call pt_resize first");
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_accum, rgba, (size_t)ctx->width * ctx->height * 16, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_resolve(pt_ctx* ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "no image: call pt_resize first");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_resolve(ctx);
+}
+
+int pt_ray_count(pt_ctx* ctx, uint64_t* rays)
+{
+    if (!ctx || !rays) return PT_ERR_INVALID;
+    unsigned long long v = 0;
+    PT_HIP(ctx, hipMemcpyAsync(&v, ctx->d_total_rays, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *rays = v;
+    return finish_timing(ctx);
+}
+
+int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out)
+{
+    if (!ctx || !out) return PT_ERR_INVALID;
+    if (ctx->timing_pending) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = finish_timing(ctx);
+        if (rc) return rc;
+    }
+    *out = ctx->timing;
+    return PT_OK;
+}
+
+void* pt_stream(pt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+void* pt_device_image(pt_ctx* ctx) { return ctx ? (void*)ctx->d_image : nullptr; }
+void* pt_device_accum(pt_ctx* ctx) { return ctx ? (void*)ctx->d_accum : nullptr; }
+
+int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters)
+{
+    if (!ctx || (n && (!rays || !hits))) return PT_ERR_INVALID;
+    if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_debug_intersect: hierarchy missing");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return debug_intersect(ctx, rays, n, hits, counters);
+}
+
+int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n)
+{
+    if (!ctx || (n && (!x || !out))) return PT_ERR_INVALID;
+    if (fn < 0 || fn > 4 || (fn == 4 && !y)) return set_error(ctx, PT_ERR_INVALID, "pt_debug_math: bad function id");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return debug_math(ctx, fn, x, y, out, n);
+}
+
+int pt_debug_disney_sample(pt_ctx* ctx, uint32_t n, const float* surf, const float* V, const float* N,
+                           uint32_t* seeds, float* f, float* L, float* pdf)
+{
+    if (!ctx || (n && (!surf || !V || !N || !seeds || !f || !L || !pdf))) return PT_ERR_INVALID;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return debug_disney(ctx, true, n, surf, V, N, nullptr, seeds, f, L, pdf);
+}
+
+int pt_debug_disney_eval(pt_ctx* ctx, uint32_t n, const float* surf, const float* V, const float* N,
+                         const float* L, float* f, float* pdf)
+{
+    if (!ctx || (n && (!surf || !V || !N || !L || !f || !pdf))) return PT_ERR_INVALID;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return debug_disney(ctx, false, n, surf, V, N, L, nullptr, f, nullptr, pdf);
+}
+
+int pt_debug_read_bvh(pt_ctx* ctx, uint32_t* nodes, uint32_t* tris)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_debug_read_bvh: hierarchy missing");
+    if (nodes && ctx->num_nodes) PT_HIP(ctx, hipMemcpyAsync(nodes, ctx->d_nodes, (size_t)ctx->num_nodes * 128, hipMemcpyDeviceToHost, ctx->stream));
+    if (tris && ctx->num_tris) PT_HIP(ctx, hipMemcpyAsync(tris, ctx->d_tris, (size_t)ctx->num_tris * 48, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+} // extern "C"

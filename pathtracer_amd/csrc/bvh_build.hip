@@ -1,0 +1,431 @@
+// GPU build of the ray-tracing hierarchy: the replacement for the driver-built BLAS/TLAS the
+// reference requests in CreateAccelerationStructure() (PathTracer/src/RayTracingLayer.cpp:342-348;
+// one TLAS instance per submesh, instance custom index = submesh index, ClosestHit.glsl:147-150).
+//
+// Pipeline (all on the context's stream):
+//   1. k_world_tris   every submesh triangle -> world space (object-to-world 3x4), its box, scene bounds
+//   2. k_morton       63-bit Morton code of the box centre
+//   3. radix sort     (rocPRIM via hipcub) of (code, triangle)
+//   4. k_karras       binary radix tree over the sorted codes (Karras 2012), duplicates split by index
+//   5. k_refit        bottom-up boxes and subtree triangle counts; the second child to arrive continues
+//   6. k_collapse     level by level: binary tree -> 4-wide nodes of 128 bytes, subtrees of <= 4 triangles
+//                     become leaves, triangles are written out in leaf order
+#include "pt_context.h"
+#include "pt_math.h"
+#include <hipcub/hipcub.hpp>
+
+namespace ptd {
+
+static constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ int f2ord(float f)
+{
+    int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void k_init_bounds(int* bounds)
+{
+    if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
+}
+
+// object-to-world: ((m0*x + m1*y) + m2*z) + m3, no fused operations
+__device__ __forceinline__ v3 xform_point(const float* __restrict__ m, v3 p)
+{
+    return V3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3],
+              m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+
+__global__ void k_world_tris(uint32_t n, uint32_t ns, const uint32_t* __restrict__ sub_tri_offset,
+                             const uint32_t* __restrict__ submeshes, const float* __restrict__ xforms,
+                             const uint32_t* __restrict__ indices, const float* __restrict__ vertices,
+                             TriRec* __restrict__ tris, float4* __restrict__ tlo, float4* __restrict__ thi, int* bounds)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    if (g < n) {
+        // submesh s with sub_tri_offset[s] <= g < sub_tri_offset[s+1]
+        uint32_t a = 0, b = ns;
+        while (b - a > 1) {
+            uint32_t m = (a + b) >> 1;
+            if (sub_tri_offset[m] <= g) a = m; else b = m;
+        }
+        uint32_t s = a, prim = g - sub_tri_offset[s];
+        uint32_t vo = submeshes[s * 4 + 1], io = submeshes[s * 4 + 2];
+        const float* m = xforms + s * 12;
+        v3 w[3];
+        for (int k = 0; k < 3; k++) {
+            uint32_t vi = indices[io + prim * 3 + k] + vo;
+            const float* v = vertices + (size_t)vi * 12;
+            w[k] = xform_point(m, V3(v[0], v[1], v[2]));
+        }
+        TriRec t;
+        t.v0x = w[0].x; t.v0y = w[0].y; t.v0z = w[0].z; t.submesh = s;
+        t.v1x = w[1].x; t.v1y = w[1].y; t.v1z = w[1].z; t.prim = prim;
+        t.v2x = w[2].x; t.v2y = w[2].y; t.v2z = w[2].z; t.pad = 0;
+        tris[g] = t;
+        lo[0] = fminf(fminf(w[0].x, w[1].x), w[2].x); hi[0] = fmaxf(fmaxf(w[0].x, w[1].x), w[2].x);
+        lo[1] = fminf(fminf(w[0].y, w[1].y), w[2].y); hi[1] = fmaxf(fmaxf(w[0].y, w[1].y), w[2].y);
+        lo[2] = fminf(fminf(w[0].z, w[1].z), w[2].z); hi[2] = fmaxf(fmaxf(w[0].z, w[1].z), w[2].z);
+        tlo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        thi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    // scene bounds: wave reduction, one atomic per wave and component
+    for (int k = 0; k < 3; k++) {
+        float l = lo[k], h = hi[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            l = fminf(l, __shfl_xor(l, off));
+            h = fmaxf(h, __shfl_xor(h, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (l <= h) {
+                atomicMin(&bounds[k], f2ord(l));
+                atomicMax(&bounds[3 + k], f2ord(h));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21(uint32_t v)
+{
+    unsigned long long x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void k_morton(uint32_t n, const float4* __restrict__ tlo, const float4* __restrict__ thi, const int* __restrict__ bounds,
+                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float blx = ord2f(bounds[0]), bly = ord2f(bounds[1]), blz = ord2f(bounds[2]);
+    float bhx = ord2f(bounds[3]), bhy = ord2f(bounds[4]), bhz = ord2f(bounds[5]);
+    float ext = fmaxf(fmaxf(bhx - blx, bhy - bly), bhz - blz);
+    float scale = ext > 0.0f ? 2097152.0f / ext : 0.0f;
+    float4 lo = tlo[g], hi = thi[g];
+    float cx = ((lo.x + hi.x) * 0.5f - blx) * scale;
+    float cy = ((lo.y + hi.y) * 0.5f - bly) * scale;
+    float cz = ((lo.z + hi.z) * 0.5f - blz) * scale;
+    uint32_t ix = (uint32_t)fminf(fmaxf(cx, 0.0f), 2097151.0f);
+    uint32_t iy = (uint32_t)fminf(fmaxf(cy, 0.0f), 2097151.0f);
+    uint32_t iz = (uint32_t)fminf(fmaxf(cz, 0.0f), 2097151.0f);
+    keys[g] = (spread21(ix) << 2) | (spread21(iy) << 1) | spread21(iz);
+    vals[g] = g;
+}
+
+// common-prefix length of sorted keys i and j (j may be out of range)
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+// internal node i of the binary radix tree; node ids: internal 0..n-2, leaf j -> (n-1)+j
+__global__ void k_karras(int n, const unsigned long long* __restrict__ keys, uint2* __restrict__ children, uint32_t* __restrict__ parent)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    uint32_t left = (lo == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
+    uint32_t right = (hi == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    children[i] = make_uint2(left, right);
+    parent[left] = (uint32_t)i;
+    parent[right] = (uint32_t)i;
+    if (i == 0) parent[0] = NONE;
+}
+
+// b2lo.w carries the subtree's triangle count (as bits)
+__global__ void k_refit(int n, const uint32_t* __restrict__ vals, const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                        const uint2* __restrict__ children, const uint32_t* __restrict__ parent, uint32_t* flags,
+                        float4* b2lo, float4* b2hi)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t t = vals[j];
+    float4 lo = tlo[t], hi = thi[t];
+    uint32_t node = (uint32_t)(n - 1 + j);
+    lo.w = __uint_as_float(1u);
+    b2lo[node] = lo;
+    b2hi[node] = hi;
+    if (n == 1) return;
+    uint32_t cur = parent[node];
+    while (cur != NONE) {
+        __threadfence();                       // publish this subtree's box before announcing arrival
+        uint32_t old = atomicAdd(&flags[cur], 1u);
+        if (old == 0) return;                  // the sibling subtree is not finished: its thread continues
+        __threadfence();                       // see the sibling's box
+        uint2 ch = children[cur];
+        float4 llo = b2lo[ch.x], lhi = b2hi[ch.x];
+        float4 rlo = b2lo[ch.y], rhi = b2hi[ch.y];
+        float4 nlo = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z),
+                                 __uint_as_float(__float_as_uint(llo.w) + __float_as_uint(rlo.w)));
+        float4 nhi = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
+        b2lo[cur] = nlo;
+        b2hi[cur] = nhi;
+        cur = parent[cur];
+    }
+}
+
+__device__ __forceinline__ float box_area(float4 lo, float4 hi)
+{
+    float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+    return ex * ey + ey * ez + ez * ex;
+}
+
+struct CollapseItem { uint32_t node2, slot, tstart, pad; };
+
+// one thread per frontier item: builds one Node4 and queues its internal children
+__global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in, CollapseItem* __restrict__ out, uint32_t* out_count,
+                           uint32_t* node_counter, uint32_t* leaf_counter, int n, const uint2* __restrict__ children,
+                           const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, const uint32_t* __restrict__ vals,
+                           const TriRec* __restrict__ tris_in, TriRec* __restrict__ tris_out, Node4* __restrict__ nodes, float pad)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nitems) return;
+    CollapseItem it = in[g];
+    uint32_t cand[4];
+    int nc;
+    auto count_of = [&](uint32_t id) { return __float_as_uint(b2lo[id].w); };
+    auto is_leaf2 = [&](uint32_t id) { return id >= (uint32_t)(n - 1); };
+    if (is_leaf2(it.node2) || count_of(it.node2) <= PT_LEAF_MAX) {
+        cand[0] = it.node2;   // only the root can get here: the whole scene fits one leaf
+        nc = 1;
+    } else {
+        uint2 ch = children[it.node2];
+        cand[0] = ch.x; cand[1] = ch.y;
+        nc = 2;
+        while (nc < 4) {
+            int bestk = -1;
+            float besta = -1.0f;
+            for (int k = 0; k < nc; k++) {
+                if (is_leaf2(cand[k]) || count_of(cand[k]) <= PT_LEAF_MAX) continue;
+                float a = box_area(b2lo[cand[k]], b2hi[cand[k]]);
+                if (a > besta) { besta = a; bestk = k; }
+            }
+            if (bestk < 0) break;
+            uint2 c2 = children[cand[bestk]];
+            cand[bestk] = c2.x;
+            cand[nc++] = c2.y;
+        }
+    }
+    Node4 nd;
+    uint32_t tstart = it.tstart;
+    for (int k = 0; k < 4; k++) {
+        if (k >= nc) {
+            nd.lox[k] = nd.loy[k] = nd.loz[k] = __builtin_inff();
+            nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -__builtin_inff();
+            nd.child[k] = PT_CHILD_EMPTY;
+            continue;
+        }
+        uint32_t c = cand[k];
+        float4 lo = b2lo[c], hi = b2hi[c];
+        uint32_t cnt = __float_as_uint(lo.w);
+        nd.lox[k] = lo.x - pad; nd.loy[k] = lo.y - pad; nd.loz[k] = lo.z - pad;
+        nd.hix[k] = hi.x + pad; nd.hiy[k] = hi.y + pad; nd.hiz[k] = hi.z + pad;
+        if (cnt <= PT_LEAF_MAX) {
+            nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
+            // write the subtree's triangles in depth-first order
+            uint32_t stack[8];
+            int sp = 0;
+            uint32_t w = tstart;
+            stack[sp++] = c;
+            while (sp) {
+                uint32_t id = stack[--sp];
+                if (is_leaf2(id)) {
+                    tris_out[w++] = tris_in[vals[id - (uint32_t)(n - 1)]];
+                } else {
+                    uint2 c2 = children[id];
+                    stack[sp++] = c2.y;
+                    stack[sp++] = c2.x;
+                }
+            }
+            atomicAdd(leaf_counter, 1u);
+        } else {
+            uint32_t slot = atomicAdd(node_counter, 1u);
+            nd.child[k] = slot;
+            uint32_t o = atomicAdd(out_count, 1u);
+            out[o] = CollapseItem{c, slot, tstart, 0u};
+        }
+        tstart += cnt;
+    }
+    nd.pad[0] = nd.pad[1] = nd.pad[2] = nd.pad[3] = 0;
+    nodes[it.slot] = nd;
+}
+
+// surface-area-heuristic cost: sum over nodes of area(child box)/area(root) * (1 for a node, count for a leaf)
+__global__ void k_sah(uint32_t num_nodes, const Node4* __restrict__ nodes, float root_area, float* cost)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    float c = 0.0f;
+    if (g < num_nodes) {
+        const Node4& nd = nodes[g];
+        for (int k = 0; k < 4; k++) {
+            uint32_t ch = nd.child[k];
+            if (ch == PT_CHILD_EMPTY) continue;
+            float ex = nd.hix[k] - nd.lox[k], ey = nd.hiy[k] - nd.loy[k], ez = nd.hiz[k] - nd.loz[k];
+            float a = (ex * ey + ey * ez + ez * ex) / root_area;
+            if (ch & PT_CHILD_LEAF) c += a * (float)(((ch >> 28) & 7u) + 1u);
+            else c += a;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c != 0.0f) atomicAdd(cost, c);
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+int build_accel(pt_ctx* ctx, uint32_t flags)
+{
+    (void)flags;
+    hipStream_t st = ctx->stream;
+    uint32_t n = ctx->num_tris;
+    if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
+    if (ctx->d_tris) { (void)hipFree(ctx->d_tris); ctx->d_tris = nullptr; }
+    ctx->accel_built = false;
+    ctx->num_nodes = 0;
+    pt_accel_stats& stats = ctx->accel_stats;
+    stats = pt_accel_stats{};
+    stats.num_triangles = n;
+    if (n == 0) { ctx->accel_built = true; return PT_OK; }
+    if (n > 0x0FFFFFFFu) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^28-1 triangles");
+
+    hipEvent_t e0, e1;
+    PT_HIP(ctx, hipEventCreate(&e0));
+    PT_HIP(ctx, hipEventCreate(&e1));
+    PT_HIP(ctx, hipEventRecord(e0, st));
+
+    DevBuf<TriRec> tris_tmp;
+    DevBuf<float4> tlo, thi, b2lo, b2hi;
+    DevBuf<int> bounds;
+    DevBuf<unsigned long long> keys, keys_sorted;
+    DevBuf<uint32_t> vals, vals_sorted, parent, flagsb, counters;
+    DevBuf<uint2> children;
+    DevBuf<CollapseItem> fr[2];
+    DevBuf<char> sort_tmp;
+    DevBuf<float> cost;
+    PT_HIP(ctx, tris_tmp.alloc(n));
+    PT_HIP(ctx, tlo.alloc(n));
+    PT_HIP(ctx, thi.alloc(n));
+    PT_HIP(ctx, b2lo.alloc(2 * (size_t)n));
+    PT_HIP(ctx, b2hi.alloc(2 * (size_t)n));
+    PT_HIP(ctx, bounds.alloc(6));
+    PT_HIP(ctx, keys.alloc(n));
+    PT_HIP(ctx, keys_sorted.alloc(n));
+    PT_HIP(ctx, vals.alloc(n));
+    PT_HIP(ctx, vals_sorted.alloc(n));
+    PT_HIP(ctx, parent.alloc(2 * (size_t)n));
+    PT_HIP(ctx, flagsb.alloc(n));
+    PT_HIP(ctx, counters.alloc(8));
+    PT_HIP(ctx, children.alloc(n));
+    PT_HIP(ctx, fr[0].alloc(n));
+    PT_HIP(ctx, fr[1].alloc(n));
+    PT_HIP(ctx, cost.alloc(1));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, (size_t)n * sizeof(Node4)));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_tris, (size_t)n * sizeof(TriRec)));
+
+    const int B = 256;
+    uint32_t G = (n + B - 1) / B;
+    k_init_bounds<<<1, 64, 0, st>>>(bounds.p);
+    k_world_tris<<<G, B, 0, st>>>(n, ctx->num_submeshes, ctx->d_sub_tri_offset, ctx->d_submeshes, ctx->d_xforms,
+                                  ctx->d_indices, ctx->d_vertices, tris_tmp.p, tlo.p, thi.p, bounds.p);
+    k_morton<<<G, B, 0, st>>>(n, tlo.p, thi.p, bounds.p, keys.p, vals.p);
+    size_t tmp_bytes = 0;
+    PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
+    PT_HIP(ctx, sort_tmp.alloc(tmp_bytes));
+    PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
+    PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
+    PT_HIP(ctx, hipMemsetAsync(parent.p, 0xFF, 2 * (size_t)n * sizeof(uint32_t), st));
+    if (n > 1) k_karras<<<G, B, 0, st>>>((int)n, keys_sorted.p, children.p, parent.p);
+    k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, tlo.p, thi.p, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p);
+
+    // padding of every child box: covers the rounding of the slab test and of the triangle test's t
+    int hb[6];
+    PT_HIP(ctx, hipMemcpyAsync(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    auto o2f = [](int i) { uint32_t u = (uint32_t)(i >= 0 ? i : i ^ 0x7fffffff); float f; memcpy(&f, &u, 4); return f; };
+    float lo[3] = {o2f(hb[0]), o2f(hb[1]), o2f(hb[2])}, hi[3] = {o2f(hb[3]), o2f(hb[4]), o2f(hb[5])};
+    float diag = sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    float mc = 0.0f;
+    for (int k = 0; k < 3; k++) mc = fmaxf(mc, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+    float pad = fmaxf(diag, mc) * (1.0f / 262144.0f);
+    if (!(pad == pad) || pad > 3.0e38f) return set_error(ctx, PT_ERR_INVALID, "scene bounds are not finite");
+
+    // collapse: counters[0] = nodes allocated, [1] = leaves, [2],[3] = frontier sizes (ping-pong)
+    uint32_t init[4] = {1u, 0u, 0u, 0u};
+    PT_HIP(ctx, hipMemcpyAsync(counters.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    CollapseItem root{0u, 0u, 0u, 0u};
+    if (n == 1) root.node2 = 0u;   // the single leaf has id n-1 = 0
+    PT_HIP(ctx, hipMemcpyAsync(fr[0].p, &root, sizeof(root), hipMemcpyHostToDevice, st));
+    uint32_t nitems = 1, depth = 0;
+    int cur = 0;
+    while (nitems > 0) {
+        depth++;
+        PT_HIP(ctx, hipMemsetAsync(counters.p + 2 + (cur ^ 1), 0, sizeof(uint32_t), st));
+        k_collapse<<<(nitems + 63) / 64, 64, 0, st>>>(nitems, fr[cur].p, fr[cur ^ 1].p, counters.p + 2 + (cur ^ 1), counters.p, counters.p + 1,
+                                                     (int)n, children.p, b2lo.p, b2hi.p, vals_sorted.p, tris_tmp.p, ctx->d_tris, ctx->d_nodes, pad);
+        PT_HIP(ctx, hipMemcpyAsync(&nitems, counters.p + 2 + (cur ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        cur ^= 1;
+        if (depth > 4096) return set_error(ctx, PT_ERR_BVH_DEPTH, "hierarchy collapse did not terminate");
+    }
+    uint32_t hc[2];
+    PT_HIP(ctx, hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    ctx->num_nodes = hc[0];
+    stats.num_nodes = hc[0];
+    stats.num_leaves = hc[1];
+    stats.max_depth = depth;
+
+    float root_area;
+    {
+        float ex = hi[0] - lo[0] + 2 * pad, ey = hi[1] - lo[1] + 2 * pad, ez = hi[2] - lo[2] + 2 * pad;
+        root_area = ex * ey + ey * ez + ez * ex;
+    }
+    PT_HIP(ctx, hipMemsetAsync(cost.p, 0, sizeof(float), st));
+    if (root_area > 0.0f) k_sah<<<(ctx->num_nodes + B - 1) / B, B, 0, st>>>(ctx->num_nodes, ctx->d_nodes, root_area, cost.p);
+    PT_HIP(ctx, hipMemcpyAsync(&stats.sah_cost, cost.p, sizeof(float), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipEventRecord(e1, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventElapsedTime(&stats.build_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+
+    if (3u * depth + 1u > (uint32_t)(16 + 80))
+        return set_error(ctx, PT_ERR_BVH_DEPTH, "hierarchy has " + std::to_string(depth) + " levels; the traversal stack holds 96 entries (32 levels)");
+    ctx->accel_built = true;
+    return PT_OK;
+}
+
+} // namespace ptd

@@ -1,0 +1,636 @@
+// Wavefront path tracing kernels: the replacement for the reference's ray-tracing pipeline
+// (RayGen / ClosestHit / Miss shaders run by vkCmdTraceRaysKHR, PathTracer/src/RayTracingLayer.cpp:274-281).
+//
+//   k_raygen   RayGen.glsl:312-345   per-pixel seed, first camera ray, path state
+//   k_extend   RayGen.glsl:124       closest hit of every queued ray (pt_traverse.h)
+//   k_shade    Miss.glsl:8-29, ClosestHit.glsl:144-226, RayGen.glsl:126-173, Disney.glsl:150-359
+//              sky on a miss, surface fetch, emission, BSDF sample, throughput, next ray,
+//              Russian roulette; finished paths either start the pixel's next sample or
+//              write the pixel (RayGen.glsl:347-372); survivors are compacted into the
+//              next queue with one ballot + one atomic per wave
+//   k_finish   adds the frame's queue sizes to the ray counter
+//
+// A pixel owns one path at a time (the reference's samples of a pixel are sequential in the RNG
+// state, RayGen.glsl:314-345), so path state is indexed by pixel; rays and hits are indexed by
+// queue slot so that every round reads and writes them densely.
+#include "pt_bsdf.h"
+#include "pt_context.h"
+#include "pt_traverse.h"
+#include <cstring>
+
+namespace ptd {
+
+static constexpr int EXT_BLOCK = 64;     // one wave per workgroup: its LDS stack is PT_STACK_LDS * 64 * 8 bytes
+static constexpr int SHADE_BLOCK = 256;
+static constexpr uint32_t MISS = 0xFFFFFFFFu;
+
+struct Queues {
+    float4* rayO_in; float4* rayD_in;
+    float4* rayO_out; float4* rayD_out;
+    float4* hits;
+    float4* stA; float4* stB; float4* stC;
+    uint32_t* counts;       // counts[r] = rays queued for round r
+    uint2* primary;
+    float* image; float* accum;
+};
+
+PT_DEV v3 mat_mul_dir(const float* m, float x, float y, float z, float w, float& ow)
+{
+    v3 r;
+    r.x = m[0] * x + m[4] * y + m[8] * z + m[12] * w;
+    r.y = m[1] * x + m[5] * y + m[9] * z + m[13] * w;
+    r.z = m[2] * x + m[6] * y + m[10] * z + m[14] * w;
+    ow = m[3] * x + m[7] * y + m[11] * z + m[15] * w;
+    return r;
+}
+
+// RayGen.glsl:322-342
+PT_DEV void camera_ray(const TraceParams& P, uint32_t x, uint32_t y, uint32_t sample, uint32_t& seed, v3& o, v3& d)
+{
+    float pcx = (float)x + 0.5f, pcy = (float)y + 0.5f;
+    if (sample > 0) {
+        float angle = random_value(seed) * 2.0f * PT_PI;
+        float s, c;
+        det_sincos(angle, s, c);
+        float r = fsqrt(random_value(seed));
+        pcx += c * r;
+        pcy += s * r;
+    }
+    float u = fdiv(pcx, (float)P.width), v = fdiv(pcy, (float)P.height);
+    float dx = u * 2.0f - 1.0f, dy = v * 2.0f - 1.0f;
+    float tw;
+    v3 target = mat_mul_dir(P.inv_proj, dx, dy, 1.0f, 1.0f, tw);
+    v3 tn = normalize(target / tw);
+    float dw;
+    v3 dir = mat_mul_dir(P.inv_view, tn.x, tn.y, tn.z, 0.0f, dw);
+    o = V3(P.inv_view[12], P.inv_view[13], P.inv_view[14]);
+    d = normalize(dir);
+}
+
+// slot -> pixel: 8x8 pixel tiles, one tile per wave, so a wave's primary rays are a compact bundle
+PT_DEV bool slot_to_pixel(uint32_t slot, uint32_t W, uint32_t H, uint32_t& x, uint32_t& y)
+{
+    uint32_t tiles_x = (W + 7u) >> 3;
+    uint32_t tile = slot >> 6, l = slot & 63u;
+    uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    x = tx * 8u + (l & 7u);
+    y = ty * 8u + (l >> 3);
+    return x < W && y < H;
+}
+
+// appends the lanes with `alive` to the queue counted by *counter; returns the slot
+PT_DEV uint32_t wave_append(bool alive, uint32_t* counter)
+{
+    unsigned long long mask = __ballot(alive);
+    if (mask == 0) return 0;
+    uint32_t lane = threadIdx.x & 63u;
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
+{
+    uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
+    uint32_t nslots = tiles * 64u;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nslots; base += gridDim.x * blockDim.x) {
+        uint32_t slot = base + threadIdx.x;
+        uint32_t x = 0, y = 0;
+        bool valid = slot < nslots && slot_to_pixel(slot, P.width, P.height, x, y);
+        v3 o = V3(0.0f), d = V3(0.0f);
+        uint32_t pixel = 0;
+        if (valid) {
+            pixel = x + y * P.width;
+            uint32_t seed = pixel * P.frame;           // RayGen.glsl:314-315
+            camera_ray(P, x, y, 0, seed, o, d);
+            q.stA[pixel] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
+            q.stB[pixel] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
+        }
+        uint32_t out = wave_append(valid, &q.counts[0]);
+        if (valid) {
+            q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
+            q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
+        }
+    }
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, float tmax, const uint32_t* __restrict__ count,
+                                                       const float4* __restrict__ rayO, const float4* __restrict__ rayD,
+                                                       float4* __restrict__ hits, unsigned long long* stats)
+{
+    __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
+    uint32_t n = *count;
+    uint32_t sn = 0, st = 0;
+    for (uint32_t base = blockIdx.x * EXT_BLOCK; base < n; base += gridDim.x * EXT_BLOCK) {
+        uint32_t slot = base + threadIdx.x;
+        if (slot < n) {
+            float4 ro = rayO[slot], rd = rayD[slot];
+            HitRec h = traverse<STATS>(sc.nodes, sc.tris, sc.num_tris, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), tmin, tmax,
+                                       stack + threadIdx.x, EXT_BLOCK, sn, st);
+            hits[slot] = make_float4(h.t, h.u, h.v, u2f(h.tri));
+        }
+    }
+    if (STATS) {
+        atomicAdd(&stats[0], (unsigned long long)sn);
+        atomicAdd(&stats[1], (unsigned long long)st);
+    }
+}
+
+// texture(sampler2D, uv): bilinear, repeat, level 0, RGBA8 UNORM
+PT_DEV float4 sample_texture(const SceneView& sc, int tex, float u, float v)
+{
+    const uint32_t* tt = sc.tex_table + tex * 4;
+    uint32_t off = tt[0], w = tt[1], h = tt[2];
+    const uint32_t* px = reinterpret_cast<const uint32_t*>(sc.tex_pool) + off;
+    float uu = u - floorf(u), vv = v - floorf(v);
+    if (!(uu >= 0.0f)) uu = 0.0f;
+    if (!(vv >= 0.0f)) vv = 0.0f;
+    float x = uu * (float)w - 0.5f, y = vv * (float)h - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    if (x0 < 0) x0 = (int)w - 1;
+    if (y0 < 0) y0 = (int)h - 1;
+    if (x1 >= (int)w) x1 = 0;
+    if (y1 >= (int)h) y1 = 0;
+    if (x0 >= (int)w) x0 = 0;
+    if (y0 >= (int)h) y0 = 0;
+    uint32_t p00 = px[(size_t)y0 * w + x0], p10 = px[(size_t)y0 * w + x1];
+    uint32_t p01 = px[(size_t)y1 * w + x0], p11 = px[(size_t)y1 * w + x1];
+    float out[4];
+    for (int ch = 0; ch < 4; ch++) {
+        const float k = 1.0f / 255.0f;
+        float c00 = (float)((p00 >> (8 * ch)) & 255u) * k, c10 = (float)((p10 >> (8 * ch)) & 255u) * k;
+        float c01 = (float)((p01 >> (8 * ch)) & 255u) * k, c11 = (float)((p11 >> (8 * ch)) & 255u) * k;
+        out[ch] = mix(mix(c00, c10, fx), mix(c01, c11, fx), fy);
+    }
+    return make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// texture(samplerCube, d).rgb: z wins ties, then y; bilinear inside the face, clamp to edge
+PT_DEV v3 sample_env(const SceneView& sc, v3 d)
+{
+    float ax = gabs(d.x), ay = gabs(d.y), az = gabs(d.z);
+    int face;
+    float s_c, t_c, ma;
+    if (az >= ax && az >= ay) {
+        ma = az;
+        if (d.z < 0.0f) { face = 5; s_c = -d.x; t_c = -d.y; } else { face = 4; s_c = d.x; t_c = -d.y; }
+    } else if (ay >= ax) {
+        ma = ay;
+        if (d.y < 0.0f) { face = 3; s_c = d.x; t_c = -d.z; } else { face = 2; s_c = d.x; t_c = d.z; }
+    } else {
+        ma = ax;
+        if (d.x < 0.0f) { face = 1; s_c = d.z; t_c = -d.y; } else { face = 0; s_c = -d.z; t_c = -d.y; }
+    }
+    float n = (float)sc.env_n;
+    float s = 0.5f * (fdiv(s_c, ma) + 1.0f), t = 0.5f * (fdiv(t_c, ma) + 1.0f);
+    float x = s * n - 0.5f, y = t * n - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    if (!(x0f == x0f)) x0f = 0.0f;
+    if (!(y0f == y0f)) y0f = 0.0f;
+    int N = (int)sc.env_n;
+    float top = (float)(N - 1);
+    int x0 = x0f < 0.0f ? 0 : (x0f > top ? N - 1 : (int)x0f);
+    int x1 = (x0f + 1.0f) < 0.0f ? 0 : ((x0f + 1.0f) > top ? N - 1 : (int)(x0f + 1.0f));
+    int y0 = y0f < 0.0f ? 0 : (y0f > top ? N - 1 : (int)y0f);
+    int y1 = (y0f + 1.0f) < 0.0f ? 0 : ((y0f + 1.0f) > top ? N - 1 : (int)(y0f + 1.0f));
+    const float4* base = reinterpret_cast<const float4*>(sc.env) + (size_t)face * N * N;
+    float4 c00 = base[(size_t)y0 * N + x0], c10 = base[(size_t)y0 * N + x1];
+    float4 c01 = base[(size_t)y1 * N + x0], c11 = base[(size_t)y1 * N + x1];
+    return V3(mix(mix(c00.x, c10.x, fx), mix(c01.x, c11.x, fx), fy),
+              mix(mix(c00.y, c10.y, fx), mix(c01.y, c11.y, fx), fy),
+              mix(mix(c00.z, c10.z, fx), mix(c01.z, c11.z, fx), fy));
+}
+
+// ClosestHit.glsl:144-226: what the payload needs downstream
+PT_DEV void fetch_surface(const SceneView& sc, uint32_t submesh, uint32_t prim, float hu, float hv, v3 rayDir,
+                          Surf& s, v3& emission, v3& worldNormal)
+{
+    const uint32_t* sm = sc.submeshes + submesh * 4;
+    uint32_t vertexOffset = sm[1], indexOffset = sm[2], materialIndex = sm[3];
+    const float* M = sc.materials + (size_t)materialIndex * 22;
+    const float* o2w = sc.xforms + submesh * 12;
+
+    float bary[3] = {1.0f - hu - hv, hu, hv};
+    float uvx = 0.0f, uvy = 0.0f;
+    v3 nrm = V3(0.0f);
+    for (int i = 0; i < 3; i++) {
+        uint32_t idx = sc.indices[prim * 3 + i + indexOffset] + vertexOffset;
+        const float* v = sc.vertices + (size_t)idx * 12;
+        uvx += v[3] * bary[i];
+        uvy += v[4] * bary[i];
+        nrm = nrm + V3(v[5], v[6], v[7]) * bary[i];
+    }
+    nrm = normalize(nrm);
+    // mat3(gl_ObjectToWorldEXT) * normal -- not the inverse transpose (ClosestHit.glsl:170)
+    worldNormal = normalize(V3(o2w[0] * nrm.x + o2w[1] * nrm.y + o2w[2] * nrm.z,
+                               o2w[4] * nrm.x + o2w[5] * nrm.y + o2w[6] * nrm.z,
+                               o2w[8] * nrm.x + o2w[9] * nrm.y + o2w[10] * nrm.z));
+    v3 view = normalize(-rayDir);
+
+    v3 albedoTex = V3(1.0f);
+    int albedoMap = (int)f2u(M[10]);
+    int mrMap = (int)f2u(M[11]);
+    if (albedoMap != -1) {
+        float4 t = sample_texture(sc, albedoMap, uvx, uvy);
+        albedoTex = V3(t.x, t.y, t.z);
+    }
+    float mrx = 1.0f, mry = 1.0f;
+    if (mrMap != -1) {
+        float4 t = sample_texture(sc, mrMap, uvx, uvy);
+        mrx = t.z;   // .bg: metallic = blue, roughness = green (ClosestHit.glsl:182)
+        mry = t.y;
+    }
+    s.albedo = V3(M[0], M[1], M[2]) * albedoTex;
+    s.roughness = M[4] * mry;
+    s.metallic = M[3] * mrx;
+    emission = V3(M[5], M[6], M[7]) * M[8];
+    float anisotropic = M[13];
+    s.subsurface = M[14];
+    s.specularTint = M[15];
+    s.sheen = M[16];
+    s.sheenTint = M[17];
+    s.clearcoat = M[18];
+    s.clearcoatRoughness = M[19];
+    s.specTrans = M[20];
+    s.ior = M[21];
+    float aspect = fsqrt(1.0f - anisotropic * 0.9f);
+    s.ax = gmax(0.001f, fdiv(s.roughness, aspect));
+    s.ay = gmax(0.001f, s.roughness * aspect);
+    s.eta = dot(view, worldNormal) < 0.0f ? fdiv(1.0f, s.ior) : s.ior;
+}
+
+// RayGen.glsl:347-372
+PT_DEV void write_pixel(const TraceParams& P, const Queues& q, uint32_t pixel, v3 color)
+{
+    float numPaths = (float)P.spp;
+    float4* acc = reinterpret_cast<float4*>(q.accum) + pixel;
+    if (P.frame > 1) {
+        float4 data = *acc;
+        color = color + V3(data.x, data.y, data.z);
+        numPaths = data.w + (float)P.spp;
+        *acc = make_float4(color.x, color.y, color.z, numPaths);
+    } else {
+        *acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    color = color / numPaths;
+    float4* img = reinterpret_cast<float4*>(q.image) + pixel;
+    if (color.x != color.x || color.y != color.y || color.z != color.z) *img = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
+    else *img = make_float4(color.x, color.y, color.z, 1.0f);
+}
+
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
+{
+    uint32_t n = q.counts[round];
+    for (uint32_t base = blockIdx.x * SHADE_BLOCK; base < n; base += gridDim.x * SHADE_BLOCK) {
+        uint32_t slot = base + threadIdx.x;
+        bool valid = slot < n;
+        bool alive = false;
+        v3 o = V3(0.0f), d = V3(0.0f);
+        uint32_t pixel = 0;
+        if (valid) {
+            float4 ro = q.rayO_in[slot], rd = q.rayD_in[slot], h = q.hits[slot];
+            pixel = f2u(ro.w);
+            o = V3(ro.x, ro.y, ro.z);
+            d = V3(rd.x, rd.y, rd.z);
+            float4 A = q.stA[pixel], B = q.stB[pixel];
+            v3 thr = V3(A.x, A.y, A.z), rad = V3(B.x, B.y, B.z);
+            uint32_t seed = f2u(A.w);
+            uint32_t bs = f2u(B.w);
+            uint32_t bounce = bs & 0xFFFFu, sample = bs >> 16;
+            uint32_t tri = f2u(h.w);
+            bool done = false;
+            if (tri == MISS) {
+                if (bounce == 0 && sample == 0) q.primary[pixel] = make_uint2(MISS, MISS);
+                v3 sky = sample_env(sc, d) * P.sky_scale;            // RayGen.glsl:128-135
+                rad = rad + sky * thr;
+                done = true;
+            } else {
+                const TriRec* tr = sc.tris + tri;
+                uint32_t submesh = tr->submesh, prim = tr->prim;
+                if (bounce == 0 && sample == 0) q.primary[pixel] = make_uint2(submesh, prim);
+                Surf s;
+                v3 emission, N;
+                fetch_surface(sc, submesh, prim, h.y, h.z, d, s, emission, N);
+                rad = rad + emission * thr;                           // RayGen.glsl:137
+                bool last_bounce = bounce + 1 >= P.max_bounces;
+                if (last_bounce && sample + 1 >= P.spp) {
+                    done = true;    // nothing after this point can reach the pixel: skip the BSDF
+                } else {
+                    v3 negD = -d;
+                    v3 ff = dot(negD, N) < 0.0f ? -N : N;             // RayGen.glsl:147
+                    v3 L;
+                    float pdf;
+                    v3 f = disney_sample(s, negD, ff, L, pdf, seed);
+                    if (pdf > 0.0f) thr = thr * (f / pdf);            // RayGen.glsl:149-152
+                    else done = true;
+                    if (!done) {
+                        v3 fhp = o + d * h.x;                         // RayGen.glsl:156-160
+                        d = L;
+                        o = fhp + d * P.eps;
+                        if (P.rr_depth > 0 && bounce >= P.rr_depth) { // RayGen.glsl:163-173
+                            float qq = gmin(gmax(thr.x, gmax(thr.y, thr.z)) + 0.001f, 0.95f);
+                            if (random_value(seed) > qq) done = true;
+                            else thr = thr / qq;
+                        }
+                    }
+                    if (last_bounce) done = true;
+                    bounce++;
+                }
+            }
+            if (done) {
+                v3 color = sample > 0 ? V3(q.stC[pixel].x, q.stC[pixel].y, q.stC[pixel].z) : V3(0.0f);
+                color = color + rad;                                  // RayGen.glsl:344
+                sample++;
+                if (sample < P.spp) {
+                    q.stC[pixel] = make_float4(color.x, color.y, color.z, 0.0f);
+                    uint32_t x = pixel % P.width, y = pixel / P.width;
+                    camera_ray(P, x, y, sample, seed, o, d);
+                    thr = V3(1.0f);
+                    rad = V3(0.0f);
+                    bounce = 0;
+                    alive = true;
+                } else {
+                    write_pixel(P, q, pixel, color);
+                }
+            } else {
+                alive = true;
+            }
+            if (alive) {
+                q.stA[pixel] = make_float4(thr.x, thr.y, thr.z, u2f(seed));
+                q.stB[pixel] = make_float4(rad.x, rad.y, rad.z, u2f(bounce | (sample << 16)));
+            }
+        }
+        uint32_t out = wave_append(alive, &q.counts[round + 1]);
+        if (alive) {
+            q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
+            q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
+        }
+    }
+}
+
+__global__ void k_finish(const uint32_t* counts, uint32_t rounds, unsigned long long* total)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long s = 0;
+        for (uint32_t r = 0; r < rounds; r++) s += counts[r];
+        *total += s;
+    }
+}
+
+__global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __restrict__ image)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float4 a = reinterpret_cast<const float4*>(accum)[g];
+    v3 c = V3(a.x, a.y, a.z) / a.w;
+    float4 out = (c.x != c.x || c.y != c.y || c.z != c.z) ? make_float4(1.0f, 0.0f, 0.0f, 1.0f) : make_float4(c.x, c.y, c.z, 1.0f);
+    reinterpret_cast<float4*>(image)[g] = out;
+}
+
+SceneView scene_view(const pt_ctx* ctx)
+{
+    SceneView sv;
+    sv.vertices = ctx->d_vertices;
+    sv.indices = ctx->d_indices;
+    sv.submeshes = ctx->d_submeshes;
+    sv.xforms = ctx->d_xforms;
+    sv.materials = ctx->d_materials;
+    sv.tex_pool = ctx->d_tex_pool;
+    sv.tex_table = ctx->d_tex_table;
+    sv.env = ctx->d_env;
+    sv.env_n = ctx->env_n;
+    sv.num_tris = ctx->num_tris;
+    sv.nodes = ctx->d_nodes;
+    sv.tris = ctx->d_tris;
+    return sv;
+}
+
+int launch_trace(pt_ctx* ctx, uint32_t frame)
+{
+    hipStream_t st = ctx->stream;
+    const pt_params& pp = ctx->params;
+    uint32_t npix = ctx->width * ctx->height;
+    uint32_t rounds = pp.spp_per_frame * pp.max_bounces;
+    TraceParams P;
+    P.width = ctx->width; P.height = ctx->height;
+    P.spp = pp.spp_per_frame; P.max_bounces = pp.max_bounces; P.rr_depth = pp.rr_depth;
+    P.sky_scale = pp.sky_scale; P.eps = pp.eps; P.tmin = pp.tmin; P.tmax = pp.tmax;
+    P.frame = frame;
+    std::memcpy(P.inv_view, ctx->camera + 48, 64);
+    std::memcpy(P.inv_proj, ctx->camera + 64, 64);
+    SceneView sv = scene_view(ctx);
+
+    const bool prof = ctx->profiling;
+    size_t need_events = 2 + 2 * (size_t)rounds + 1;
+    if (prof) {
+        while (ctx->events.size() < need_events) {
+            hipEvent_t e;
+            PT_HIP(ctx, hipEventCreate(&e));
+            ctx->events.push_back(e);
+        }
+    }
+    size_t ev = 0;
+    auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
+
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (rounds + 1) * sizeof(uint32_t), st));
+    Queues q;
+    q.hits = ctx->d_hits;
+    q.stA = ctx->d_stA; q.stB = ctx->d_stB; q.stC = ctx->d_stC;
+    q.counts = ctx->d_counts;
+    q.primary = ctx->d_primary;
+    q.image = ctx->d_image; q.accum = ctx->d_accum;
+
+    uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
+    PT_HIP(ctx, mark());
+    {
+        q.rayO_in = q.rayO_out = ctx->d_rayO[0];
+        q.rayD_in = q.rayD_out = ctx->d_rayD[0];
+        uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
+        uint32_t blocks = (tiles * 64u + 255u) / 256u;
+        if (blocks > max_blocks) blocks = max_blocks;
+        k_raygen<<<blocks, 256, 0, st>>>(P, q);
+    }
+    PT_HIP(ctx, mark());
+    uint32_t ext_blocks = (npix + EXT_BLOCK - 1) / EXT_BLOCK;
+    uint32_t ext_cap = (uint32_t)ctx->num_cus * 20u;
+    if (ext_blocks > ext_cap) ext_blocks = ext_cap;
+    uint32_t sh_blocks = (npix + SHADE_BLOCK - 1) / SHADE_BLOCK;
+    if (sh_blocks > max_blocks) sh_blocks = max_blocks;
+    for (uint32_t r = 0; r < rounds; r++) {
+        int in = (int)(r & 1u), out = in ^ 1;
+        k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
+        PT_HIP(ctx, mark());
+        q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
+        q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
+        k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
+        PT_HIP(ctx, mark());
+    }
+    k_finish<<<1, 64, 0, st>>>(ctx->d_counts, rounds, ctx->d_total_rays);
+    PT_HIP(ctx, mark());
+    PT_HIP(ctx, hipGetLastError());
+    ctx->timing_rounds = rounds;
+    ctx->timing_pending = prof;
+    return PT_OK;
+}
+
+int launch_resolve(pt_ctx* ctx)
+{
+    uint32_t n = ctx->width * ctx->height;
+    k_resolve<<<(n + 255) / 256, 256, 0, ctx->stream>>>(n, ctx->d_accum, ctx->d_image);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// ---- inspection hooks --------------------------------------------------------------------------
+__global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uint32_t n, const float4* __restrict__ rays,
+                                                                uint32_t* __restrict__ out, unsigned long long* stats)
+{
+    __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
+    uint32_t sn = 0, st = 0;
+    for (uint32_t base = blockIdx.x * EXT_BLOCK; base < n; base += gridDim.x * EXT_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        if (i < n) {
+            float4 ro = rays[2 * i], rd = rays[2 * i + 1];
+            HitRec h = traverse<true>(sc.nodes, sc.tris, sc.num_tris, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, rd.w,
+                                      stack + threadIdx.x, EXT_BLOCK, sn, st);
+            uint32_t* o = out + (size_t)i * 5;
+            if (h.tri == MISS) { o[0] = f2u(rd.w); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }
+            else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = h.submesh; o[4] = h.prim; }
+        }
+    }
+    atomicAdd(&stats[0], (unsigned long long)sn);
+    atomicAdd(&stats[1], (unsigned long long)st);
+}
+
+__global__ void k_debug_math(int fn, uint32_t n, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    switch (fn) {
+    case 0: det_sincos(x[i], s, c); out[i] = s; break;
+    case 1: det_sincos(x[i], s, c); out[i] = c; break;
+    case 2: out[i] = det_log(x[i]); break;
+    case 3: out[i] = det_exp(x[i]); break;
+    default: out[i] = det_pow(x[i], y[i]); break;
+    }
+}
+
+PT_DEV Surf surf_from(const float* s)
+{
+    Surf p;
+    p.albedo = V3(s[0], s[1], s[2]);
+    p.metallic = s[3]; p.roughness = s[4]; p.subsurface = s[5]; p.specularTint = s[6];
+    p.sheen = s[7]; p.sheenTint = s[8]; p.clearcoat = s[9]; p.clearcoatRoughness = s[10];
+    p.specTrans = s[11]; p.ior = s[12]; p.ax = s[13]; p.ay = s[14]; p.eta = s[15];
+    return p;
+}
+
+__global__ void k_debug_disney(bool sample, uint32_t n, const float* __restrict__ surf, const float* __restrict__ V,
+                               const float* __restrict__ N, const float* __restrict__ Lin, uint32_t* seeds,
+                               float* __restrict__ f, float* __restrict__ Lout, float* __restrict__ pdf)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Surf p = surf_from(surf + (size_t)i * 17);
+    v3 v = V3(V[3 * i], V[3 * i + 1], V[3 * i + 2]), nn = V3(N[3 * i], N[3 * i + 1], N[3 * i + 2]);
+    float pd;
+    v3 r;
+    if (sample) {
+        uint32_t seed = seeds[i];
+        v3 L;
+        r = disney_sample(p, v, nn, L, pd, seed);
+        seeds[i] = seed;
+        Lout[3 * i] = L.x; Lout[3 * i + 1] = L.y; Lout[3 * i + 2] = L.z;
+    } else {
+        r = disney_eval(p, v, nn, V3(Lin[3 * i], Lin[3 * i + 1], Lin[3 * i + 2]), pd);
+    }
+    f[3 * i] = r.x; f[3 * i + 1] = r.y; f[3 * i + 2] = r.z;
+    pdf[i] = pd;
+}
+
+template <class T>
+struct Tmp {
+    T* p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters)
+{
+    hipStream_t st = ctx->stream;
+    Tmp<float4> d_rays;
+    Tmp<uint32_t> d_out;
+    PT_HIP(ctx, d_rays.alloc(2 * (size_t)n));
+    PT_HIP(ctx, d_out.alloc(5 * (size_t)n));
+    PT_HIP(ctx, hipMemcpyAsync(d_rays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 16, st));
+    uint32_t blocks = (n + EXT_BLOCK - 1) / EXT_BLOCK;
+    uint32_t cap = (uint32_t)ctx->num_cus * 20u;
+    if (blocks > cap) blocks = cap;
+    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, d_rays.p, d_out.p, ctx->d_stats);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipMemcpyAsync(hits, d_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, st));
+    unsigned long long hs[2] = {0, 0};
+    PT_HIP(ctx, hipMemcpyAsync(hs, ctx->d_stats, 16, hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    if (counters) { counters[0] = hs[0]; counters[1] = hs[1]; }
+    return PT_OK;
+}
+
+int debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n)
+{
+    hipStream_t st = ctx->stream;
+    Tmp<float> dx, dy, dout;
+    PT_HIP(ctx, dx.alloc(n));
+    PT_HIP(ctx, dy.alloc(n));
+    PT_HIP(ctx, dout.alloc(n));
+    PT_HIP(ctx, hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (y) PT_HIP(ctx, hipMemcpyAsync(dy.p, y, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    else PT_HIP(ctx, hipMemsetAsync(dy.p, 0, (size_t)n * 4, st));
+    if (n) k_debug_math<<<(n + 255) / 256, 256, 0, st>>>(fn, n, dx.p, dy.p, dout.p);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    return PT_OK;
+}
+
+int debug_disney(pt_ctx* ctx, bool sample, uint32_t n, const float* surf, const float* V, const float* N,
+                 const float* Lin, uint32_t* seeds, float* f, float* Lout, float* pdf)
+{
+    hipStream_t st = ctx->stream;
+    Tmp<float> dsurf, dV, dN, dL, df, dLo, dpdf;
+    Tmp<uint32_t> dseed;
+    PT_HIP(ctx, dsurf.alloc((size_t)n * 17));
+    PT_HIP(ctx, dV.alloc((size_t)n * 3));
+    PT_HIP(ctx, dN.alloc((size_t)n * 3));
+    PT_HIP(ctx, dL.alloc((size_t)n * 3));
+    PT_HIP(ctx, df.alloc((size_t)n * 3));
+    PT_HIP(ctx, dLo.alloc((size_t)n * 3));
+    PT_HIP(ctx, dpdf.alloc(n));
+    PT_HIP(ctx, dseed.alloc(n));
+    PT_HIP(ctx, hipMemcpyAsync(dsurf.p, surf, (size_t)n * 68, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(dV.p, V, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(dN.p, N, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    if (Lin) PT_HIP(ctx, hipMemcpyAsync(dL.p, Lin, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    if (seeds) PT_HIP(ctx, hipMemcpyAsync(dseed.p, seeds, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (n) k_debug_disney<<<(n + 255) / 256, 256, 0, st>>>(sample, n, dsurf.p, dV.p, dN.p, dL.p, dseed.p, df.p, dLo.p, dpdf.p);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipMemcpyAsync(f, df.p, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipMemcpyAsync(pdf, dpdf.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (sample) {
+        PT_HIP(ctx, hipMemcpyAsync(Lout, dLo.p, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemcpyAsync(seeds, dseed.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    }
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    return PT_OK;
+}
+
+} // namespace ptd

@@ -1,0 +1,213 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE: imported only by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+
+
+def _has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    name = "liboracle.so" if _has_fma() else "liboracle_nofma.so"
+    path = os.path.join(_ORACLE_DIR, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp, fp, up = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.orc_create.restype = vp
+    L.orc_create.argtypes = [vp]
+    L.orc_destroy.argtypes = [vp]
+    L.orc_destroy.restype = None
+    L.orc_update_materials.argtypes = [vp, fp, C.c_uint32]
+    L.orc_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.orc_set_camera.argtypes = [vp, fp]
+    L.orc_set_params.argtypes = [vp, vp]
+    L.orc_trace.argtypes = [vp, C.c_uint32, C.c_int, C.c_int]
+    L.orc_read_image.argtypes = [vp, fp]
+    L.orc_read_accum.argtypes = [vp, fp]
+    L.orc_write_accum.argtypes = [vp, fp]
+    L.orc_read_primary_ids.argtypes = [vp, up]
+    L.orc_ray_count.argtypes = [vp]
+    L.orc_ray_count.restype = C.c_uint64
+    L.orc_traversal_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.orc_traversal_stats.restype = None
+    L.orc_num_triangles.argtypes = [vp]
+    L.orc_num_triangles.restype = C.c_uint32
+    L.orc_intersect.argtypes = [vp, fp, C.c_uint32, up, C.c_int, C.c_int]
+    L.orc_pcg_hash.argtypes = [up]
+    L.orc_pcg_hash.restype = C.c_uint32
+    L.orc_random_value.argtypes = [up]
+    L.orc_random_value.restype = C.c_float
+    L.orc_det_math.argtypes = [C.c_int, fp, fp, fp, C.c_uint32]
+    L.orc_det_math.restype = None
+    L.orc_disney_sample.argtypes = [fp, fp, fp, up, fp, fp, fp]
+    L.orc_disney_sample.restype = None
+    L.orc_disney_eval.argtypes = [fp, fp, fp, fp, fp, fp]
+    L.orc_disney_eval.restype = None
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Oracle:
+    """CPU restatement of the reference's path tracer over one scene."""
+
+    def __init__(self, scene, threads=None):
+        self.L = lib()
+        self.scene = scene
+        desc, keep = scene.as_desc()      # same struct layout as the product's pt_scene_desc
+        self.h = self.L.orc_create(C.byref(desc))
+        del keep
+        self.threads = threads or min(os.cpu_count() or 1, 16)
+        self.width = self.height = 0
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resize(self, w, h):
+        self.L.orc_resize(self.h, w, h)
+        self.width, self.height = w, h
+
+    def set_camera(self, m):
+        m = np.ascontiguousarray(m, np.float32).reshape(-1)
+        self.L.orc_set_camera(self.h, _fp(m))
+
+    def set_params(self, params):
+        self.L.orc_set_params(self.h, C.byref(params))
+
+    def update_materials(self, m):
+        m = np.ascontiguousarray(m, np.float32)
+        assert self.L.orc_update_materials(self.h, _fp(m), m.size // 22) == 0
+
+    def trace(self, frame, use_bvh=True):
+        assert self.L.orc_trace(self.h, frame, self.threads, 1 if use_bvh else 0) == 0
+
+    def read_image(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self.L.orc_read_image(self.h, _fp(out))
+        return out
+
+    def read_accum(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self.L.orc_read_accum(self.h, _fp(out))
+        return out
+
+    def write_accum(self, a):
+        a = np.ascontiguousarray(a, np.float32)
+        self.L.orc_write_accum(self.h, _fp(a))
+
+    def read_primary_ids(self):
+        out = np.empty((self.height, self.width, 2), np.uint32)
+        self.L.orc_read_primary_ids(self.h, _up(out))
+        return out
+
+    def ray_count(self):
+        return int(self.L.orc_ray_count(self.h))
+
+    def traversal_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.orc_traversal_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def num_triangles(self):
+        return int(self.L.orc_num_triangles(self.h))
+
+    def intersect(self, rays, use_bvh=True):
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.empty((len(r), 5), np.uint32)
+        self.L.orc_intersect(self.h, _fp(r), len(r), _up(hits), 1 if use_bvh else 0, self.threads)
+        return hits
+
+
+def pcg_hash(seed):
+    s = C.c_uint32(seed)
+    v = lib().orc_pcg_hash(C.byref(s))
+    return v, s.value
+
+
+def random_value(seed):
+    s = C.c_uint32(seed)
+    v = lib().orc_random_value(C.byref(s))
+    return v, s.value
+
+
+def det_math(fn, x, y=None):
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    y = np.zeros_like(x) if y is None else np.ascontiguousarray(y, np.float32).reshape(-1)
+    out = np.empty_like(x)
+    lib().orc_det_math(fn, _fp(x), _fp(y), _fp(out), len(x))
+    return out
+
+
+def disney_sample(surf, V, N, seeds):
+    surf = np.ascontiguousarray(surf, np.float32).reshape(-1, 17)
+    n = len(surf)
+    V = np.ascontiguousarray(V, np.float32).reshape(n, 3)
+    N = np.ascontiguousarray(N, np.float32).reshape(n, 3)
+    seeds = np.array(seeds, np.uint32).reshape(n).copy()
+    f = np.empty((n, 3), np.float32)
+    L = np.empty((n, 3), np.float32)
+    pdf = np.empty(n, np.float32)
+    Lb = lib()
+    for i in range(n):
+        s = C.c_uint32(int(seeds[i]))
+        p = C.c_float()
+        Lb.orc_disney_sample(_fp(surf[i]), _fp(V[i]), _fp(N[i]), C.byref(s), _fp(f[i]), _fp(L[i]), C.byref(p))
+        seeds[i] = s.value
+        pdf[i] = p.value
+    return f, L, pdf, seeds
+
+
+def disney_eval(surf, V, N, Lin):
+    surf = np.ascontiguousarray(surf, np.float32).reshape(-1, 17)
+    n = len(surf)
+    V = np.ascontiguousarray(V, np.float32).reshape(n, 3)
+    N = np.ascontiguousarray(N, np.float32).reshape(n, 3)
+    Lin = np.ascontiguousarray(Lin, np.float32).reshape(n, 3)
+    f = np.empty((n, 3), np.float32)
+    pdf = np.empty(n, np.float32)
+    Lb = lib()
+    for i in range(n):
+        p = C.c_float()
+        Lb.orc_disney_eval(_fp(surf[i]), _fp(V[i]), _fp(N[i]), _fp(Lin[i]), _fp(f[i]), C.byref(p))
+        pdf[i] = p.value
+    return f, pdf
