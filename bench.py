@@ -1,0 +1,231 @@
+"""Throughput benchmark of the path-tracing hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pt_trace frame (1 sample per pixel, up to `bounces` ray segments per path) of the
+workload named in config.workload.  Every rank holds the whole scene and hierarchy and renders its
+own stripe of frame indices (weak scaling: K frames per rank); at N > 1 the accumulation images are
+summed with one RCCL reduce inside the timed region.  value = ray segments traced by all ranks /
+max-over-ranks wall time, inputs resident in HBM.
+
+Also reported on the same JSON line:
+  roofline     dominant kernel (k_extend): algorithmic bytes (ray 32 B read + hit 16 B write per ray,
+               128 B per hierarchy node visited, 48 B per triangle tested; counted by the kernel's own
+               counting variant) / its average launch time from HIP events on the launch stream,
+               against the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (a port of the reference shaders, not the reference itself) on the
+               host cores, rank 0, bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 48, 32, 16
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def make_workload(name, width, height):
+    from pathtracer_amd import camera, procedural
+    from pathtracer_amd.scene import SceneData
+    if name == "sponza_class":
+        return procedural.sponza_class(), procedural.sponza_camera(width, height), \
+            "procedural Sponza-class atrium (273536 tris, 103 submeshes, 25 full-Disney materials; Sponza.bin is absent from the reference)"
+    if name == "bistro_class":
+        return procedural.bistro_class(), procedural.bistro_camera(width, height), "procedural Bistro-class street (~3M tris)"
+    if name == "cornell":
+        sc = SceneData.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
+        return sc, camera.cornell_camera(width, height), "CornellBox.gltf from the reference assets (63978 tris)"
+    raise SystemExit("unknown workload " + name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="sponza_class")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--build-flags", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pathtracer_amd import distributed as ptdist
+    from pathtracer_amd.backend import Backend
+    from pathtracer_amd.scene import Params
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    scene, cam, workload_text = make_workload(args.workload, args.width, args.height)
+    params = Params.reference(spp_per_frame=1, max_bounces=args.bounces)
+    b = Backend(local_rank)
+    b.scene_upload(scene)
+    accel = b.build_accel(args.build_flags)
+    r = ptdist.GpuRenderer(b, args.width, args.height, device)
+    b.set_camera(cam)
+    b.set_params(params)
+
+    def barrier():
+        b.sync()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # warm-up: frame 1 clears the accumulation image, the rest touch every kernel and the reduce path
+    b.trace(1)
+    frames = ptdist.stripe(rank, world, args.warmup + args.steps)
+    for f in frames[:args.warmup]:
+        b.trace(f)
+    b.sync()
+    if world > 1:
+        ptdist.merge_accumulation(r.accum.clone())
+    r.zero_accum()
+    rays0 = b.ray_count()
+
+    barrier()
+    t0 = time.perf_counter()
+    for f in frames[args.warmup:]:
+        b.trace(f)
+    b.sync()
+    if world > 1:
+        ptdist.merge_accumulation(r.accum)
+        if rank == 0:
+            b.resolve()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    rays = b.ray_count() - rays0
+    stat = torch.tensor([dt, float(rays)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = stat[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rsum = stat[1:2].clone()
+        dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+        dt_max, rays_all = float(tmax.item()), float(rsum.item())
+    else:
+        dt_max, rays_all = dt, float(rays)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: timed pass (HIP events per launch), then a counting pass ----
+        b.set_profiling(1)
+        ext_ms = ext_launches = prof_rays = 0
+        shade_ms = raygen_ms = total_ms = 0.0
+        nprof = min(8, args.steps)
+        for f in frames[args.warmup:args.warmup + nprof]:
+            b.trace(f)
+            b.sync()
+            t = b.last_trace_timing()
+            ext_ms += t.extend_ms
+            ext_launches += t.extend_launches
+            prof_rays += t.rays
+            shade_ms += t.shade_ms
+            raygen_ms += t.raygen_ms
+            total_ms += t.total_ms
+        b.set_profiling(2)
+        nodes = tris = count_rays = 0
+        for f in frames[args.warmup:args.warmup + nprof]:
+            b.trace(f)
+            b.sync()
+            t = b.last_trace_timing()
+            nodes += t.nodes_visited
+            tris += t.tris_tested
+            count_rays += t.rays
+        b.set_profiling(0)
+        alg_bytes = count_rays * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES
+        achieved = alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
+        if args.workload == "sponza_class" and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        roofline = {
+            "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4), "launches": ext_launches,
+            "alg_bytes_per_launch": int(alg_bytes / max(1, ext_launches)),
+            "bytes_per_ray": round(alg_bytes / max(1, count_rays), 1),
+            "nodes_per_ray": round(nodes / max(1, count_rays), 2), "tris_per_ray": round(tris / max(1, count_rays), 2),
+            "frame_ms": {"total": round(total_ms / nprof, 3), "raygen": round(raygen_ms / nprof, 3),
+                         "extend": round(ext_ms / nprof, 3), "shade": round(shade_ms / nprof, 3)},
+        }
+
+        # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload ----
+        cpu = None
+        if args.cpu_seconds > 0 and world == 1:
+            from tests import oracle_lib
+            threads = host_threads()
+            o = oracle_lib.Oracle(scene, threads=threads)
+            o.resize(args.width, args.height)
+            o.set_camera(cam)
+            o.set_params(params)
+            c0 = o.ray_count()
+            tc = time.perf_counter()
+            nframes = 0
+            while True:
+                o.trace(2 + nframes)
+                nframes += 1
+                if time.perf_counter() - tc >= args.cpu_seconds or nframes >= args.steps:
+                    break
+            tc = time.perf_counter() - tc
+            cpu = {"value": round((o.ray_count() - c0) / tc / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": "%d full %dx%d frames of the same scene, camera and parameters (%.1f s)" % (nframes, args.width, args.height, tc)}
+            o.close()
+
+        out = {
+            "metric": "Mrays/s (paths×bounces) per GPU + node, Sponza 1080p 8 bounces; % HBM roofline",
+            "value": round(rays_all / dt_max / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, %dx%d, 1 spp/frame, %d bounces, no Russian roulette, constant white sky x10; %s"
+                                   % (args.workload, args.width, args.height, args.bounces, workload_text),
+                       "rays_per_step_per_gpu": int(rays / args.steps), "triangles": accel.num_triangles,
+                       "hierarchy": {"nodes": accel.num_nodes, "levels": accel.max_depth, "build_ms": round(accel.build_ms, 3),
+                                     "sah_cost": round(accel.sah_cost, 2)},
+                       "parallelism": "frame-index stripes per GPU, scene replicated" + (", one RCCL reduce of the accumulation image" if world > 1 else "")},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    barrier()
+    b.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out, ensure_ascii=False), flush=True)
+
+
+if __name__ == "__main__":
+    main()

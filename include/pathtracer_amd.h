@@ -81,8 +81,10 @@ typedef struct pt_accel_stats {
 /* per-kernel device time of the last pt_trace (HIP events on the context's stream) */
 typedef struct pt_trace_timing {
     float total_ms, raygen_ms, extend_ms, shade_ms;
-    uint32_t extend_launches, shade_launches;
+    uint32_t extend_launches, shade_launches;   /* launches that had rays queued */
     uint64_t rays;             /* ray segments traced by that call */
+    uint64_t nodes_visited;    /* hierarchy nodes fetched / triangles tested by the traversal kernel; */
+    uint64_t tris_tested;      /* only counted in profiling mode 2, else 0 */
 } pt_trace_timing;
 
 typedef struct pt_ctx pt_ctx;
@@ -132,9 +134,11 @@ int pt_resolve(pt_ctx* ctx);
 int pt_read_primary_ids(pt_ctx* ctx, uint32_t* submesh_prim_pairs);
 /* number of traceRayEXT-equivalents issued since the context was created */
 int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
-/* on: every kernel launch of later pt_trace calls is bracketed by HIP events on the
- * context's stream; pt_last_trace_timing then reports the last frame's per-kernel time */
-int pt_set_profiling(pt_ctx* ctx, int on);
+/* mode 1: every kernel launch of later pt_trace calls is bracketed by HIP events on the
+ * context's stream; pt_last_trace_timing then reports the last frame's per-kernel time.
+ * mode 2: as 1, and the traversal kernel also counts the nodes and triangles it touches
+ * (slower; for the bytes-per-ray figure, not for timing).  mode 0: off. */
+int pt_set_profiling(pt_ctx* ctx, int mode);
 int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out);
 /* the HIP stream pt_trace launches on (hipStream_t as void*) */
 void* pt_stream(pt_ctx* ctx);

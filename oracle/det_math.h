@@ -11,14 +11,14 @@
 //
 //   sincos : q = rne(x * 2/pi) by the 1.5*2^23 trick; 3-term Cody-Waite reduction
 //            with fma; degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4];
-//            quadrant select.  Meant for |x| < 2^11 * pi/2.
+//            quadrant select.  Defined for |x| < 8192; anything else gives the quiet NaN 0x7fc00000.
 //   log    : x = m * 2^k, m in [sqrt(1/2), sqrt(2)); f = m-1; s = f/(2+f);
 //            ln m = f - f^2/2 + s*(f^2/2 + R(s^2)); + k*ln2 in two parts.
 //   exp    : k = rne(x / ln2); r = x - k*ln2 (two-part, fma); degree-6 polynomial;
 //            scaling by 2^k in two exact steps.
 //   pow    : exp(y * log(x))   (GLSL: pow(x,y) undefined for x < 0).
 //
-// Accuracy (checked in tests/test_det_math.py against float64 libm): <= 2 ulp for
+// Accuracy (checked in tests/test_oracle_kat.py against float64 libm): <= 2 ulp for
 // sin/cos on [0, 2*pi], log on (0, 1e30), exp on [-87, 88].
 #pragma once
 #include <cmath>
@@ -42,6 +42,10 @@ static inline void det_sincos(float x, float* s_out, float* c_out)
     const float P1 = 0x1.921p+0f;                  // pi/2 = P1 + P2 + P3 (P1, P2: 13 bits)
     const float P2 = 0x1.f6ap-13f;
     const float P3 = 0x1.110b46p-26f;
+    if (!(u2f(f2u(x) & 0x7fffffffu) < 8192.0f)) {   // outside the reduction's range, inf or NaN: one fixed quiet NaN
+        *s_out = *c_out = u2f(0x7fc00000u);
+        return;
+    }
     float qf = (x * TWO_OVER_PI + MAGIC) - MAGIC;
     float r = fmaf(qf, -P1, x);
     r = fmaf(qf, -P2, r);

@@ -35,7 +35,8 @@ class AccelStats(C.Structure):
 
 class TraceTiming(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("raygen_ms", C.c_float), ("extend_ms", C.c_float), ("shade_ms", C.c_float),
-                ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("rays", C.c_uint64)]
+                ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("rays", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
 
 
 _lib = None
@@ -189,8 +190,9 @@ class Backend:
         self._check(self.lib.pt_ray_count(self.h, C.byref(v)))
         return v.value
 
-    def set_profiling(self, on):
-        self._check(self.lib.pt_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, mode):
+        """0 off, 1 per-kernel HIP-event timing, 2 timing + traversal node/triangle counters."""
+        self._check(self.lib.pt_set_profiling(self.h, int(mode)))
 
     def last_trace_timing(self):
         t = TraceTiming()

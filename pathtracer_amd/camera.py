@@ -38,9 +38,10 @@ def look_at(eye, target, up=(0.0, 1.0, 0.0)):
 
 def from_pitch_yaw(position, pitch, yaw):
     """View matrix from the reference's CameraSpecification{pitch, yaw} (RayTracingLayer.cpp:38-42):
-    yaw about +Y, then pitch about the camera's X axis, forward = -Z at pitch = yaw = 0."""
+    yaw about +Y measured from +Z towards +X, positive pitch looks down (the engine's own
+    convention is unknown; with this one the commented Sponza pose looks down the nave)."""
     cp, sp, cy, sy = math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
-    forward = np.array([-sy * cp, -sp, -cy * cp])
+    forward = np.array([sy * cp, -sp, cy * cp])
     return look_at(position, np.asarray(position, np.float64) + forward)
 
 

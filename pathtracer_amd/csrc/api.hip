@@ -77,6 +77,12 @@ static int finish_timing(pt_ctx* ctx)
     }
     PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[2 + 2 * R]));
     t.total_ms = ms;
+    if (ctx->profiling == 2) {
+        unsigned long long hs[2] = {0, 0};
+        PT_HIP(ctx, hipMemcpy(hs, ctx->d_stats, 16, hipMemcpyDeviceToHost));
+        t.nodes_visited = hs[0];
+        t.tris_tested = hs[1];
+    }
     ctx->timing = t;
     return PT_OK;
 }
@@ -307,10 +313,16 @@ int pt_set_params(pt_ctx* ctx, const pt_params* p)
     return PT_OK;
 }
 
-int pt_set_profiling(pt_ctx* ctx, int on)
+int pt_set_profiling(pt_ctx* ctx, int mode)
 {
     if (!ctx) return PT_ERR_INVALID;
-    ctx->profiling = on != 0;
+    if (mode < 0 || mode > 2) return set_error(ctx, PT_ERR_INVALID, "pt_set_profiling: mode must be 0, 1 or 2");
+    if (ctx->timing_pending) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = finish_timing(ctx);
+        if (rc) return rc;
+    }
+    ctx->profiling = mode;
     return PT_OK;
 }
 

@@ -58,7 +58,7 @@ struct pt_ctx {
     bool camera_set = false;
 
     // per-kernel timing of the last frame
-    bool profiling = false;
+    int profiling = 0;           // 0 off, 1 events, 2 events + traversal counters
     std::vector<hipEvent_t> events;
     pt_trace_timing timing{};
     uint32_t timing_rounds = 0;

@@ -7,7 +7,8 @@
 // sequences below instead of the device library, so that a CPU restatement using
 // the same sequences reproduces the kernels' output bit for bit:
 //   sincos : q = rne(x * 2/pi) via the 1.5*2^23 trick, three-term Cody-Waite
-//            reduction with fma, degree-7/8 polynomials on [-pi/4, pi/4]
+//            reduction with fma, degree-7/8 polynomials on [-pi/4, pi/4]; |x| >= 8192, inf
+//            and NaN give the quiet NaN 0x7fc00000
 //   log    : x = m * 2^k, m in [sqrt(1/2), sqrt(2)), s = f/(2+f) series
 //   exp    : k = rne(x / ln2), two-part reduction, degree-6 polynomial, 2^k in two
 //            exact factors
@@ -41,6 +42,10 @@ PT_DEV void det_sincos(float x, float& s_out, float& c_out)
     const float P1 = 0x1.921p+0f;
     const float P2 = 0x1.f6ap-13f;
     const float P3 = 0x1.110b46p-26f;
+    if (!(gabs(x) < 8192.0f)) {   // outside the reduction's range, inf or NaN: one fixed quiet NaN
+        s_out = c_out = u2f(0x7fc00000u);
+        return;
+    }
     float qf = (x * TWO_OVER_PI + MAGIC) - MAGIC;
     float r = fmaf(qf, -P1, x);
     r = fmaf(qf, -P2, r);

@@ -427,7 +427,8 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     std::memcpy(P.inv_proj, ctx->camera + 64, 64);
     SceneView sv = scene_view(ctx);
 
-    const bool prof = ctx->profiling;
+    const bool prof = ctx->profiling != 0;
+    const bool counting = ctx->profiling == 2;
     size_t need_events = 2 + 2 * (size_t)rounds + 1;
     if (prof) {
         while (ctx->events.size() < need_events) {
@@ -440,6 +441,7 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
 
     PT_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (rounds + 1) * sizeof(uint32_t), st));
+    if (counting) PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 16, st));
     Queues q;
     q.hits = ctx->d_hits;
     q.stA = ctx->d_stA; q.stB = ctx->d_stB; q.stC = ctx->d_stC;
@@ -465,7 +467,10 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     if (sh_blocks > max_blocks) sh_blocks = max_blocks;
     for (uint32_t r = 0; r < rounds; r++) {
         int in = (int)(r & 1u), out = in ^ 1;
-        k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
+        if (counting)
+            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_stats);
+        else
+            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
         PT_HIP(ctx, mark());
         q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
         q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];

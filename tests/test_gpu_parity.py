@@ -1,0 +1,401 @@
+"""Parity of the HIP backend (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Bar: bit-exact.  Integer results (primary-hit ids, ray counts) must be equal, and because both sides
+evaluate every floating-point result with the same IEEE operation sequence (see pathtracer_amd/csrc/
+pt_math.h and oracle/det_math.h), radiance, accumulation and BSDF values are compared as raw bits too:
+the stated fp32 tolerance is 0 ulp.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import camera, procedural
+from pathtracer_amd.backend import BackendError
+from pathtracer_amd.scene import Params, SceneData, make_material
+from tests import oracle_lib
+from tests.conftest import GOLDEN, random_frames, random_rays, random_surfaces
+
+pytestmark = pytest.mark.gpu
+
+M32 = 0xFFFFFFFF
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def render_pair(backend, scene, cam, W, H, frames, upload=True, **params):
+    p = Params.reference(**params)
+    if upload:
+        backend.scene_upload(scene)
+        backend.build_accel()
+    backend.resize(W, H)
+    backend.set_camera(cam)
+    backend.set_params(p)
+    o = oracle_lib.Oracle(scene)
+    o.resize(W, H)
+    o.set_camera(cam)
+    o.set_params(p)
+    r0 = backend.ray_count()
+    for f in frames:
+        backend.trace(f)
+        o.trace(f)
+    return o, backend.ray_count() - r0
+
+
+def assert_same_frame(backend, o, rays_gpu):
+    assert np.array_equal(backend.read_primary_ids(), o.read_primary_ids())
+    assert rays_gpu == o.ray_count()
+    assert np.array_equal(bits(backend.read_accum()), bits(o.read_accum()))
+    assert np.array_equal(bits(backend.read_image()), bits(o.read_image()))
+
+
+# ---- function level -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("fn", [0, 1, 2, 3])
+def test_det_math_bit_exact(backend, fn):
+    rng = np.random.default_rng(fn)
+    x = {0: rng.uniform(0, 2 * np.pi, 200000), 1: rng.uniform(-50, 50, 200000),
+         2: np.exp(rng.uniform(-100, 88, 200000)), 3: rng.uniform(-110, 90, 200000)}[fn].astype(np.float32)
+    x[:6] = [0.0, -0.0, 1.0, np.inf, -np.inf, np.nan]
+    assert np.array_equal(bits(backend.debug_math(fn, x)), bits(oracle_lib.det_math(fn, x)))
+
+
+def test_det_pow_bit_exact(backend):
+    rng = np.random.default_rng(9)
+    x = rng.uniform(0, 1, 200000).astype(np.float32)
+    y = rng.uniform(0, 3, 200000).astype(np.float32)
+    x[:3] = [0.0, 1.0, 1e-40]
+    assert np.array_equal(bits(backend.debug_math(4, x, y)), bits(oracle_lib.det_math(4, x, y)))
+
+
+@pytest.mark.parametrize("kind", ["diffuse", "metal", "mixed", "full", "glass"])
+def test_disney_sample_and_eval_bit_exact(backend, kind):
+    rng = np.random.default_rng(hash(kind) & 0xFFFF)
+    n = 20000
+    s = random_surfaces(rng, n, kind)
+    V, N = random_frames(rng, n)
+    seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    fg, Lg, pg, sg = backend.debug_disney_sample(s, V, N, seeds)
+    fc, Lc, pc, sc = oracle_lib.disney_sample(s, V, N, seeds)
+    assert np.array_equal(sg, sc)
+    assert np.array_equal(bits(Lg), bits(Lc))
+    assert np.array_equal(bits(fg), bits(fc))
+    assert np.array_equal(bits(pg), bits(pc))
+    L = rng.normal(size=(n, 3)).astype(np.float32)
+    L /= np.linalg.norm(L, axis=1, keepdims=True)
+    fg, pg = backend.debug_disney_eval(s, V, N, L)
+    fc, pc = oracle_lib.disney_eval(s, V, N, L)
+    assert np.array_equal(bits(fg), bits(fc)) and np.array_equal(bits(pg), bits(pc))
+
+
+def test_disney_degenerate_inputs_bit_exact(backend):
+    # black albedo, eta = 1, roughness 0, grazing and back-facing view vectors, normal at the pole
+    s = np.zeros((6, 17), np.float32)
+    s[:, 12] = 1.5
+    s[:, 13:15] = 0.001
+    s[:, 15] = 1.5
+    s[1, 0:3] = 1.0
+    s[1, 15] = 1.0
+    s[1, 12] = 1.0
+    s[2, 3] = 1.0
+    s[3, 0:3] = 0.5
+    s[3, 11] = 1.0
+    s[3, 15] = 1 / 1.5
+    s[4, 0:3] = 0.7
+    s[4, 9] = 1.0
+    s[4, 10] = 1.0
+    s[5, 0:3] = 0.7
+    s[5, 9] = 1.0
+    N = np.tile(np.array([[0, 0, 1]], np.float32), (6, 1))
+    V = np.array([[0, 0, 1], [1, 0, 0], [0, 0, 1], [0.6, 0, 0.8], [0, 1, 1e-4], [0, 0, -1]], np.float32)
+    V /= np.linalg.norm(V, axis=1, keepdims=True)
+    seeds = np.arange(6, dtype=np.uint32) * 977 + 1
+    g = backend.debug_disney_sample(s, V, N, seeds)
+    c = oracle_lib.disney_sample(s, V, N, seeds)
+    for a, b in zip(g, c):
+        assert np.array_equal(bits(a), bits(b))
+
+
+# ---- traversal ---------------------------------------------------------------------------------------------
+def test_intersect_equals_brute_force_on_cornell(backend, cornell):
+    backend.scene_upload(cornell)
+    st = backend.build_accel()
+    assert st.num_triangles == cornell.num_triangles == 63978
+    rng = np.random.default_rng(21)
+    rays = random_rays(rng, 4000, [-0.3, 0.0, -0.58], [0.25, 0.53, 0.6])
+    o = oracle_lib.Oracle(cornell)
+    hg, counters = backend.debug_intersect(rays)
+    assert np.array_equal(hg, o.intersect(rays, use_bvh=False))
+    assert counters[0] > 0 and counters[1] > 0
+
+
+def test_intersect_large_batch_and_short_rays(backend, cornell):
+    backend.scene_upload(cornell)
+    backend.build_accel()
+    rng = np.random.default_rng(22)
+    o = oracle_lib.Oracle(cornell)
+    rays = random_rays(rng, 300000, [-0.35, -0.05, -0.6], [0.3, 0.6, 0.8])
+    rays[::3, 7] = rng.uniform(0.01, 0.5, len(rays[::3]))       # finite tmax
+    rays[1::5, 3] = rng.uniform(0.01, 0.3, len(rays[1::5]))     # large tmin
+    hg, _ = backend.debug_intersect(rays)
+    assert np.array_equal(hg, o.intersect(rays, use_bvh=True))
+
+
+def test_intersect_degenerate_rays(backend, cornell):
+    backend.scene_upload(cornell)
+    backend.build_accel()
+    o = oracle_lib.Oracle(cornell)
+    rays = np.array([
+        [0, 0.25, 0.5, 1e-5, 0, 0, -1, 1e27],          # axis aligned
+        [0, 0.25, 0.5, 1e-5, 0, 0, 0, 1e27],           # zero direction
+        [0, 0.25, 0.5, 1e-5, np.nan, 0, -1, 1e27],     # NaN direction
+        [np.nan, 0.25, 0.5, 1e-5, 0, 0, -1, 1e27],     # NaN origin
+        [0, 0.25, 0.5, 1e-5, 0, 1, 0, 1e27],
+        [0, 0.25, 0.5, 1e-5, 1, 0, 0, 1e27],
+        [0, 0.25, 50.0, 1e-5, 0, 0, -1, 1e27],         # far outside
+        [0, 0.25, 0.5, 1e-5, 0, 0, 1, 1e27],           # leaves through the open front
+    ], np.float32)
+    hg, _ = backend.debug_intersect(rays)
+    hc = o.intersect(rays, use_bvh=False)
+    assert np.array_equal(hg, hc)
+    assert tuple(hg[1, 3:5]) == (M32, M32) and tuple(hg[2, 3:5]) == (M32, M32) and tuple(hg[7, 3:5]) == (M32, M32)
+
+
+def test_tie_rule_and_watertight_edges(backend):
+    v = np.zeros((8, 12), np.float32)
+    quad = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)]
+    v[0:4, 0:3] = quad
+    v[4:8, 0:3] = quad
+    v[:, 5:8] = (0, 0, 1)
+    idx = np.array([0, 1, 2, 0, 2, 3, 0, 1, 2, 0, 2, 3], np.uint32)
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (2, 1))
+    sc = SceneData(v, idx, [(0, 4, 6, 0), (0, 0, 0, 0)], [6, 6], ident, [make_material()])
+    backend.scene_upload(sc)
+    st = backend.build_accel()
+    assert st.num_triangles == 4 and st.num_nodes == 1
+    o = oracle_lib.Oracle(sc)
+    rng = np.random.default_rng(1)
+    rays = random_rays(rng, 2000, [-1.2, -1.2, 0], [1.2, 1.2, 1])
+    rays[:, 4:7] = (0, 0, -1)
+    rays[:200, 0] = rays[:200, 1]                     # exactly on the shared diagonal
+    rays[200:300, 0:2] = rng.integers(-1, 2, (100, 2))  # through corners / edge midpoints
+    hg, _ = backend.debug_intersect(rays)
+    assert np.array_equal(hg, o.intersect(rays, use_bvh=False))
+    inside = (np.abs(rays[:, 0]) <= 1) & (np.abs(rays[:, 1]) <= 1)
+    assert (hg[inside, 3] == 0).all()                 # coincident submeshes: the lower submesh index wins
+    assert (hg[~inside, 3] == M32).all()
+
+
+def test_hierarchy_is_well_formed(backend, cornell):
+    backend.scene_upload(cornell)
+    st = backend.build_accel()
+    nodes, tris = backend.debug_read_bvh()
+    nf = nodes.view(np.float32)
+    seen = np.zeros(st.num_triangles, bool)
+    visited = np.zeros(st.num_nodes, bool)
+    tv = tris.view(np.float32).reshape(-1, 3, 4)[:, :, :3]
+    stack = [0]
+    while stack:
+        i = stack.pop()
+        assert not visited[i]
+        visited[i] = True
+        for k in range(4):
+            ch = int(nodes[i, 24 + k])
+            if ch == M32:
+                continue
+            lo = np.array([nf[i, k], nf[i, 4 + k], nf[i, 8 + k]])
+            hi = np.array([nf[i, 12 + k], nf[i, 16 + k], nf[i, 20 + k]])
+            if ch & 0x80000000:
+                first, cnt = ch & 0x0FFFFFFF, ((ch >> 28) & 7) + 1
+                assert cnt <= 4 and not seen[first:first + cnt].any()
+                seen[first:first + cnt] = True
+                p = tv[first:first + cnt].reshape(-1, 3)
+                assert (p >= lo).all() and (p <= hi).all()
+            else:
+                cf = nf[ch]
+                used = nodes[ch, 24:28] != M32
+                assert (cf[0:4][used] >= lo[0]).all() and (cf[12:16][used] <= hi[0]).all()
+                assert (cf[4:8][used] >= lo[1]).all() and (cf[16:20][used] <= hi[1]).all()
+                assert (cf[8:12][used] >= lo[2]).all() and (cf[20:24][used] <= hi[2]).all()
+                stack.append(ch)
+    assert seen.all() and visited.all()
+    # every (submesh, prim) appears exactly once
+    ids = tris[:, 3].astype(np.uint64) << np.uint64(32) | tris[:, 7].astype(np.uint64)
+    assert len(np.unique(ids)) == st.num_triangles
+
+
+# ---- frames --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,S,B,frames", [(128, 128, 1, 4, (1, 2, 3)), (96, 64, 5, 20, (1, 2)), (24, 16, 2, 3, (7,))])
+def test_cornell_frames_bit_exact(backend, cornell, cameras, W, H, S, B, frames):
+    o, rays = render_pair(backend, cornell, cameras["%dx%d" % (W, H)], W, H, frames, spp_per_frame=S, max_bounces=B)
+    assert_same_frame(backend, o, rays)
+
+
+def test_cornell_512_config_and_golden_ids(backend, cornell, cameras):
+    # BASELINE configs[0]: Cornell 512x512, 1 spp, 4 bounces
+    o, rays = render_pair(backend, cornell, cameras["512x512"], 512, 512, (1, 2), spp_per_frame=1, max_bounces=4)
+    assert_same_frame(backend, o, rays)
+    # 64x64 ids against the committed brute-force fixture
+    backend.resize(64, 64)
+    backend.set_camera(cameras["64x64"])
+    backend.trace(1)
+    assert np.array_equal(backend.read_primary_ids(), np.load(os.path.join(GOLDEN, "cornell_primary_ids_64.npy")))
+
+
+def test_cornell_golden_radiance(backend, cornell, cameras):
+    backend.scene_upload(cornell)
+    backend.build_accel()
+    backend.resize(128, 128)
+    backend.set_camera(cameras["128x128"])
+    backend.set_params(Params.reference(spp_per_frame=1, max_bounces=4))
+    for f in range(1, 18):
+        backend.trace(f)
+    want = np.load(os.path.join(GOLDEN, "cornell_radiance_128_16spp.npy"))
+    assert np.array_equal(bits(backend.read_accum()), bits(want))
+
+
+def test_ragged_sizes(backend, cornell):
+    backend.scene_upload(cornell)
+    backend.build_accel()
+    for (W, H) in [(1, 1), (7, 3), (9, 17), (65, 8), (8, 65)]:
+        cam = camera.cornell_camera(W, H)
+        o, rays = render_pair(backend, cornell, cam, W, H, (1, 2), upload=False, spp_per_frame=2, max_bounces=3)
+        assert_same_frame(backend, o, rays)
+
+
+def test_metal_variant_and_material_update(backend, cornell, cameras):
+    # the "metal" variant of the Cornell config: sphere material -> metallic 1, roughness 0.2
+    mats = cornell.materials.copy()
+    mats[1] = make_material(albedo=(0.9, 0.6, 0.3), metallic=1.0, roughness=0.2)
+    sc = SceneData(cornell.vertices, cornell.indices, cornell.submeshes, cornell.index_counts, cornell.xforms, mats)
+    o, rays = render_pair(backend, sc, cameras["96x64"], 96, 64, (1, 2), spp_per_frame=1, max_bounces=8)
+    assert_same_frame(backend, o, rays)
+    # UpdateMaterialData (RayTracingLayer.cpp:621): new materials, same geometry and hierarchy
+    mats2 = mats.copy()
+    mats2[0] = make_material(albedo=(0.3, 0.3, 0.8), roughness=0.4, clearcoat=1.0, clearcoat_roughness=0.1)
+    backend.update_materials(mats2)
+    o.update_materials(mats2)
+    r0, c0 = backend.ray_count(), o.ray_count()
+    for f in (1, 2, 3):
+        backend.trace(f)
+        o.trace(f)
+    assert backend.ray_count() - r0 == o.ray_count() - c0
+    assert np.array_equal(bits(backend.read_accum()), bits(o.read_accum()))
+
+
+def test_full_disney_procedural_scene(backend):
+    # small instance of the Sponza-class stand-in: clearcoat / sheen / transmission materials, scaled submeshes
+    sc = procedural.sponza_class(detail=0.05)
+    W, H = 160, 90
+    o, rays = render_pair(backend, sc, procedural.sponza_camera(W, H), W, H, (1, 2, 3), spp_per_frame=1, max_bounces=8)
+    assert_same_frame(backend, o, rays)
+    img = backend.read_image()
+    assert len(np.unique(backend.read_primary_ids()[..., 0])) > 20 and np.isfinite(img).all()
+
+
+def test_russian_roulette_option(backend, cornell, cameras):
+    o, rays = render_pair(backend, cornell, cameras["96x64"], 96, 64, (1, 2), spp_per_frame=2, max_bounces=12, rr_depth=2)
+    assert_same_frame(backend, o, rays)
+    o2, rays2 = render_pair(backend, cornell, cameras["96x64"], 96, 64, (1, 2), upload=False, spp_per_frame=2, max_bounces=12)
+    assert rays < rays2          # roulette ends paths early
+
+
+def test_textures_and_environment_map(backend, cornell, cameras):
+    rng = np.random.default_rng(5)
+    tex0 = rng.integers(0, 256, (16, 32, 4), dtype=np.uint8)
+    tex1 = rng.integers(0, 256, (5, 3, 4), dtype=np.uint8)
+    env = rng.uniform(0, 2, (6, 4, 4, 4)).astype(np.float32)
+    verts = cornell.vertices.copy()
+    verts[:, 3:5] = verts[:, 0:2] * 3.7 - 0.4        # the Cornell asset has no uv set: derive one, with wrap-around
+    mats = cornell.materials.copy()
+    mats[0] = make_material(albedo=(1, 1, 1), roughness=1.0, albedo_map=0, mr_map=1, metallic=1.0)
+    mats[1] = make_material(albedo=(1, 0.5, 0.5), roughness=0.8, albedo_map=1)
+    sc = SceneData(verts, cornell.indices, cornell.submeshes, cornell.index_counts, cornell.xforms, mats,
+                   textures=[tex0, tex1], env=env)
+    o, rays = render_pair(backend, sc, cameras["96x64"], 96, 64, (1, 2, 3), spp_per_frame=1, max_bounces=5)
+    assert_same_frame(backend, o, rays)
+
+
+def test_nan_pixels_are_red_like_the_oracle(backend, cornell, cameras):
+    mats = cornell.materials.copy()
+    mats[0] = make_material(emissive=(0, 0, 0), emissive_strength=np.inf)
+    sc = SceneData(cornell.vertices, cornell.indices, cornell.submeshes, cornell.index_counts, cornell.xforms, mats)
+    o, rays = render_pair(backend, sc, cameras["24x16"], 24, 16, (1, 2), spp_per_frame=1, max_bounces=3)
+    assert_same_frame(backend, o, rays)
+    img = backend.read_image()
+    assert (img == np.array([1, 0, 0, 1], np.float32)).all(-1).any()
+
+
+def test_empty_scene_and_single_triangle(backend):
+    ident = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], np.float32)
+    empty = SceneData(np.zeros((1, 12), np.float32), np.zeros(0, np.uint32), [(0, 0, 0, 0)], [0], ident, [make_material()])
+    cam = camera.cornell_camera(16, 8)
+    o, rays = render_pair(backend, empty, cam, 16, 8, (1, 2), spp_per_frame=1, max_bounces=4)
+    assert backend.accel.num_nodes == 0 and rays == 16 * 8 * 2
+    assert_same_frame(backend, o, rays)
+    v = np.zeros((3, 12), np.float32)
+    v[:, 0:3] = [(-1, -1, -0.5), (1, -1, -0.5), (0, 1.5, -0.5)]
+    v[:, 5:8] = (0, 0, 1)
+    one = SceneData(v, [0, 1, 2], [(0, 0, 0, 0)], [3], ident, [make_material(emissive=(1, 2, 3))])
+    o, rays = render_pair(backend, one, cam, 16, 8, (1, 2), spp_per_frame=1, max_bounces=4)
+    assert backend.accel.num_nodes == 1
+    assert_same_frame(backend, o, rays)
+
+
+# ---- size-independent properties at the full 1080p size ---------------------------------------------------------
+def test_full_size_accumulation_properties(backend, cornell, cameras):
+    W, H = 1920, 1080
+    backend.scene_upload(cornell)
+    backend.build_accel()
+    backend.resize(W, H)
+    backend.set_camera(cameras["1920x1080"])
+    backend.set_params(Params.reference(spp_per_frame=1, max_bounces=8))
+    r0 = backend.ray_count()
+    backend.trace(1)
+    assert not backend.read_accum().any()                         # frame 1 clears (RayGen.glsl:361-365)
+    n1 = backend.ray_count() - r0
+    assert W * H <= n1 <= W * H * 8
+    backend.trace(2)
+    a2 = backend.read_accum()
+    backend.trace(3)
+    a3 = backend.read_accum()
+    assert (a2[..., 3] == 1).all() and (a3[..., 3] == 2).all()
+    assert (a3[..., :3] >= a2[..., :3]).all()                     # radiance is non-negative, sums only grow
+    # idempotence: the same frame index on a restored accumulation gives the same bits
+    backend.write_accum(a2)
+    backend.trace(3)
+    assert np.array_equal(bits(backend.read_accum()), bits(a3))
+    # merge property used by the multi-GPU split: frames rendered into separate buffers add up
+    backend.write_accum(np.zeros_like(a2))
+    backend.trace(3)
+    only3 = backend.read_accum()
+    assert np.allclose(only3[..., :3] + a2[..., :3], a3[..., :3], rtol=1e-6, atol=1e-6) and (only3[..., 3] == 1).all()
+    # resolve: image = accum.rgb / accum.a
+    backend.write_accum(a3)
+    backend.resolve()
+    img = backend.read_image()
+    assert np.array_equal(bits(img[..., :3]), bits((a3[..., :3] / a3[..., 3:4]).astype(np.float32)))
+    # oracle spot check on rows of the full-size frame would take minutes; the 64x64 golden ids cover the hit path
+
+
+# ---- errors -----------------------------------------------------------------------------------------------------------
+def test_error_reporting(backend, cornell):
+    bad = SceneData(cornell.vertices, cornell.indices, cornell.submeshes.copy(), cornell.index_counts, cornell.xforms, cornell.materials)
+    bad.submeshes[0, 3] = 99
+    with pytest.raises(BackendError) as e:
+        backend.scene_upload(bad)
+    assert e.value.code == 1 and "material" in str(e.value)
+    bad2 = SceneData(cornell.vertices[:100], cornell.indices, cornell.submeshes, cornell.index_counts, cornell.xforms, cornell.materials)
+    with pytest.raises(BackendError):
+        backend.scene_upload(bad2)
+    backend.scene_upload(cornell)
+    with pytest.raises(BackendError):
+        backend.trace(1)                 # hierarchy not built after a new upload
+    backend.build_accel()
+    with pytest.raises(BackendError):
+        backend.trace(0)                 # frame index is 1-based
+    with pytest.raises(BackendError):
+        backend.set_params(Params.reference(spp_per_frame=0))
+    with pytest.raises(BackendError):
+        backend.resize(0, 4)
