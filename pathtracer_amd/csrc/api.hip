@@ -63,8 +63,11 @@ static int finish_timing(pt_ctx* ctx)
     PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
     t.raygen_ms = ms;
     // device-side queue sizes tell which rounds had work
-    std::vector<uint32_t> counts(R + 1);
-    PT_HIP(ctx, hipMemcpy(counts.data(), ctx->d_counts, (R + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> shard_counts((size_t)(R + 1) * PT_SHARDS);
+    PT_HIP(ctx, hipMemcpy(shard_counts.data(), ctx->d_counts, shard_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> counts(R + 1, 0);
+    for (uint32_t r = 0; r <= R; r++)
+        for (uint32_t k = 0; k < PT_SHARDS; k++) counts[r] += shard_counts[(size_t)r * PT_SHARDS + k];
     for (uint32_t r = 0; r < R; r++) {
         float e = 0.0f, s = 0.0f;
         PT_HIP(ctx, hipEventElapsedTime(&e, ev[1 + 2 * r], ev[2 + 2 * r]));
@@ -263,7 +266,9 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_images(ctx);
     size_t n = (size_t)width * height;
-    size_t slots = (size_t)((width + 7) / 8) * ((height + 7) / 8) * 64;
+    size_t tiles = (size_t)((width + 7) / 8) * ((height + 7) / 8);
+    ctx->shard_cap = (uint32_t)((tiles + PT_SHARDS - 1) / PT_SHARDS) * 64u;
+    size_t slots = (size_t)ctx->shard_cap * PT_SHARDS;
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_image_own, n * 16));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_accum_own, n * 16));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_primary, n * 8));
@@ -338,7 +343,7 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
     if (rounds + 1 > ctx->counts_cap) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         (void)dev_free(ctx->d_counts);
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (rounds + 1) * sizeof(uint32_t)));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (size_t)(rounds + 1) * PT_SHARDS * sizeof(uint32_t)));
         ctx->counts_cap = rounds + 1;
     }
     if (ctx->timing_pending) {   // a profiled frame is still in flight: collect it before its events are reused

@@ -48,7 +48,8 @@ struct pt_ctx {
     float4* d_stA = nullptr;
     float4* d_stB = nullptr;
     float4* d_stC = nullptr;
-    uint32_t* d_counts = nullptr;   // one per round + 1
+    uint32_t shard_cap = 0;         // ray-queue slots per shard
+    uint32_t* d_counts = nullptr;   // PT_SHARDS per round, rounds + 1 rows
     uint32_t counts_cap = 0;
     unsigned long long* d_total_rays = nullptr;
     unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested (debug intersect)

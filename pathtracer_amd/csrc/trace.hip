@@ -13,6 +13,13 @@
 // A pixel owns one path at a time (the reference's samples of a pixel are sequential in the RNG
 // state, RayGen.glsl:314-345), so path state is indexed by pixel; rays and hits are indexed by
 // queue slot so that every round reads and writes them densely.
+//
+// The ray queue is cut into PT_SHARDS independent sub-queues.  8x8-pixel tile t starts in shard
+// t % PT_SHARDS, a workgroup with blockIdx % PT_SHARDS == s only ever reads and appends to shard s,
+// and survivors stay in their shard.  A shard therefore never outgrows its initial capacity, the
+// append counters are PT_SHARDS different words instead of one (a single word serialises at about
+// 90 atomics per microsecond, which bounded the whole shade stage), and because workgroups b and
+// b + 8 share an XCD, a shard's rays, hits and path state are touched by one XCD's L2 only.
 #include "pt_bsdf.h"
 #include "pt_context.h"
 #include "pt_traverse.h"
@@ -29,7 +36,8 @@ struct Queues {
     float4* rayO_out; float4* rayD_out;
     float4* hits;
     float4* stA; float4* stB; float4* stC;
-    uint32_t* counts;       // counts[r] = rays queued for round r
+    uint32_t* counts;       // counts[r * PT_SHARDS + s] = rays queued in shard s for round r
+    uint32_t shard_cap;     // slots per shard; shard s owns slots [s * shard_cap, (s + 1) * shard_cap)
     uint2* primary;
     float* image; float* accum;
 };
@@ -108,7 +116,8 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
             q.stA[pixel] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
             q.stB[pixel] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
         }
-        uint32_t out = wave_append(valid, &q.counts[0]);
+        uint32_t shard = (slot >> 6) % PT_SHARDS;      // one tile per wave: wave-uniform
+        uint32_t out = shard * q.shard_cap + wave_append(valid, &q.counts[shard]);
         if (valid) {
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
             q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -117,16 +126,18 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, float tmax, const uint32_t* __restrict__ count,
-                                                       const float4* __restrict__ rayO, const float4* __restrict__ rayD,
+__global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, float tmax, const uint32_t* __restrict__ counts,
+                                                       uint32_t shard_cap, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                        float4* __restrict__ hits, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
-    uint32_t n = *count;
+    const uint32_t shard = blockIdx.x % PT_SHARDS, lb = blockIdx.x / PT_SHARDS, nb = gridDim.x / PT_SHARDS;
+    const uint32_t n = counts[shard];
     uint32_t sn = 0, st = 0;
-    for (uint32_t base = blockIdx.x * EXT_BLOCK; base < n; base += gridDim.x * EXT_BLOCK) {
-        uint32_t slot = base + threadIdx.x;
-        if (slot < n) {
+    for (uint32_t base = lb * EXT_BLOCK; base < n; base += nb * EXT_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t slot = shard * shard_cap + i;
+        if (i < n) {
             float4 ro = rayO[slot], rd = rayD[slot];
             HitRec h = traverse<STATS>(sc.nodes, sc.tris, sc.num_tris, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), tmin, tmax,
                                        stack + threadIdx.x, EXT_BLOCK, sn, st);
@@ -287,10 +298,11 @@ PT_DEV void write_pixel(const TraceParams& P, const Queues& q, uint32_t pixel, v
 
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
 {
-    uint32_t n = q.counts[round];
-    for (uint32_t base = blockIdx.x * SHADE_BLOCK; base < n; base += gridDim.x * SHADE_BLOCK) {
-        uint32_t slot = base + threadIdx.x;
-        bool valid = slot < n;
+    const uint32_t shard = blockIdx.x % PT_SHARDS, lb = blockIdx.x / PT_SHARDS, nb = gridDim.x / PT_SHARDS;
+    const uint32_t n = q.counts[round * PT_SHARDS + shard];
+    for (uint32_t base = lb * SHADE_BLOCK; base < n; base += nb * SHADE_BLOCK) {
+        uint32_t slot = shard * q.shard_cap + base + threadIdx.x;
+        bool valid = base + threadIdx.x < n;
         bool alive = false;
         v3 o = V3(0.0f), d = V3(0.0f);
         uint32_t pixel = 0;
@@ -367,7 +379,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
                 q.stB[pixel] = make_float4(rad.x, rad.y, rad.z, u2f(bounce | (sample << 16)));
             }
         }
-        uint32_t out = wave_append(alive, &q.counts[round + 1]);
+        uint32_t out = shard * q.shard_cap + wave_append(alive, &q.counts[(round + 1) * PT_SHARDS + shard]);
         if (alive) {
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
             q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -377,11 +389,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
 
 __global__ void k_finish(const uint32_t* counts, uint32_t rounds, unsigned long long* total)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        unsigned long long s = 0;
-        for (uint32_t r = 0; r < rounds; r++) s += counts[r];
-        *total += s;
-    }
+    // one wave: rays traced this frame = sum of all queue sizes
+    unsigned long long s = 0;
+    for (uint32_t r = threadIdx.x; r < rounds * PT_SHARDS; r += 64) s += counts[r];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) *total += s;
 }
 
 __global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __restrict__ image)
@@ -440,12 +452,13 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     size_t ev = 0;
     auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
 
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (rounds + 1) * sizeof(uint32_t), st));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(rounds + 1) * PT_SHARDS * sizeof(uint32_t), st));
     if (counting) PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 16, st));
     Queues q;
     q.hits = ctx->d_hits;
     q.stA = ctx->d_stA; q.stB = ctx->d_stB; q.stC = ctx->d_stC;
     q.counts = ctx->d_counts;
+    q.shard_cap = ctx->shard_cap;
     q.primary = ctx->d_primary;
     q.image = ctx->d_image; q.accum = ctx->d_accum;
 
@@ -460,17 +473,21 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         k_raygen<<<blocks, 256, 0, st>>>(P, q);
     }
     PT_HIP(ctx, mark());
-    uint32_t ext_blocks = (npix + EXT_BLOCK - 1) / EXT_BLOCK;
-    uint32_t ext_cap = (uint32_t)ctx->num_cus * 20u;
-    if (ext_blocks > ext_cap) ext_blocks = ext_cap;
-    uint32_t sh_blocks = (npix + SHADE_BLOCK - 1) / SHADE_BLOCK;
-    if (sh_blocks > max_blocks) sh_blocks = max_blocks;
+    // grids are multiples of PT_SHARDS: workgroup b serves shard b % PT_SHARDS
+    auto shard_grid = [](uint32_t items, uint32_t block, uint32_t cap) {
+        uint32_t per_shard = (items / PT_SHARDS + block) / block;
+        uint32_t cap_per_shard = cap / PT_SHARDS ? cap / PT_SHARDS : 1u;
+        if (per_shard > cap_per_shard) per_shard = cap_per_shard;
+        return per_shard * PT_SHARDS;
+    };
+    uint32_t ext_blocks = shard_grid(npix, EXT_BLOCK, (uint32_t)ctx->num_cus * 20u);
+    uint32_t sh_blocks = shard_grid(npix, SHADE_BLOCK, max_blocks);
     for (uint32_t r = 0; r < rounds; r++) {
         int in = (int)(r & 1u), out = in ^ 1;
         if (counting)
-            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_stats);
+            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_stats);
         else
-            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
+            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
         PT_HIP(ctx, mark());
         q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
         q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];

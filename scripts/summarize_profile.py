@@ -1,0 +1,72 @@
+"""Turns the rocprofv3 databases written by scripts/profile.sh into the summaries kept under profiles/.
+
+usage: python scripts/summarize_profile.py gpurun_out/prof_r01 r01
+writes profiles/<tag>_kernel_stats.md, profiles/<tag>_pmc.json and profiles/extend_traffic.json
+(the HBM bytes per k_extend launch that bench.py reports as roofline.traffic).
+"""
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def short(name):
+    m = re.search(r"(ptd::k_\w+(<\w+>)?|__amd_rocclr_\w+|rocprim\S*?::(\w+_kernel|trampoline_kernel))", name)
+    return m.group(1) if m else name[:60]
+
+
+db = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
+rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+lines = ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 16 --warmup 2 --cpu-seconds 0` (%s)" % tag, "",
+         "| kernel | calls | total us | average us | % |", "|---|---|---|---|---|"]
+agg = {}
+for name, calls, total, avg, pct in rows:
+    k = short(name)
+    a = agg.setdefault(k, [0, 0.0, 0.0])
+    a[0] += calls
+    a[1] += total
+    a[2] += pct
+for k, (calls, total, pct) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    lines.append("| %s | %d | %.1f | %.2f | %.2f |" % (k, calls, total, total / calls, pct))
+res = db.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels group by name").fetchall()
+lines += ["", "| kernel | vgpr | agpr | sgpr | lds B | scratch B | workgroup | grid |", "|---|---|---|---|---|---|---|---|"]
+for r in res:
+    if "ptd::" in r[0]:
+        lines.append("| %s | %s |" % (short(r[0]), " | ".join(str(x) for x in r[1:])))
+open(os.path.join(out_dir, tag + "_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
+
+pmc = {}
+for path in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_results.db"))):
+    d = sqlite3.connect(path)
+    q = "select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection group by kernel_name, counter_name"
+    for kname, cname, n, avg, total in d.execute(q):
+        if "ptd::" not in kname:
+            continue
+        pmc.setdefault(short(kname), {})[cname] = {"dispatches": n, "avg": avg, "sum": total}
+ext = pmc.get("ptd::k_extend<false>", {})
+summary = {"source": "rocprofv3 --pmc, one pass per counter group, bench.py --steps 16 --warmup 2 --cpu-seconds 0", "per_kernel": pmc}
+if "FETCH_SIZE" in ext:
+    raw_kb = ext["FETCH_SIZE"]["avg"]
+    wr_kb = ext.get("WRITE_SIZE", {}).get("avg", 0.0)
+    # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes, so wide (16 B/lane) reads are under-reported 2x
+    traffic = {"kernel": "k_extend", "fetch_kb_raw_per_launch": raw_kb, "write_kb_per_launch": wr_kb,
+               "hbm_bytes_per_launch": int((2.0 * raw_kb + wr_kb) * 1024),
+               "note": "FETCH_SIZE doubled per the gfx950 correction for 16-byte-per-lane reads; WRITE_SIZE as reported; "
+                       "Infinity-Cache hits are included in these fabric-side counters"}
+    summary["extend_traffic"] = traffic
+    json.dump(traffic, open(os.path.join(out_dir, "extend_traffic.json"), "w"), indent=1)
+if "TCC_HIT_sum" in ext and "TCC_MISS_sum" in ext:
+    h, m = ext["TCC_HIT_sum"]["sum"], ext["TCC_MISS_sum"]["sum"]
+    summary["extend_l2_hit_rate"] = h / (h + m) if h + m else None
+json.dump(summary, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
+print("\n".join(lines[:14]))
+print(json.dumps({k: v for k, v in summary.items() if k != "per_kernel"}, indent=1))
+for k, v in pmc.items():
+    print(k, {c: round(x["avg"], 1) for c, x in v.items()})
