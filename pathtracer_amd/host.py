@@ -1,0 +1,214 @@
+"""ctypes binding of the C++ host layer (libpt_host.so, include/pathtracer_host.h): glTF scene
+load, camera and the headless RayTracingLayer.  Class and method names follow the reference's
+call sites (PathTracer/src/RayTracingLayer.cpp:27-42, 350-425)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .scene import Params, SceneData
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt_host.so")
+
+EXPORTS = [
+    "pth_mesh_load", "pth_mesh_free", "pth_mesh_counts", "pth_mesh_tables", "pth_mesh_submesh_name", "pth_mesh_texture_uri",
+    "pth_mesh_set_texture", "pth_mesh_set_material", "pth_camera_matrices", "pth_layer_create", "pth_layer_destroy",
+    "pth_layer_set_viewport", "pth_layer_set_params", "pth_layer_set_accumulate", "pth_layer_set_camera_position",
+    "pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render", "pth_layer_frame_index",
+    "pth_layer_read_image", "pth_layer_read_accum", "pth_layer_ray_count", "pth_layer_last_error",
+]
+
+
+class CameraSpec(C.Structure):
+    _fields_ = [("pitch", C.c_float), ("yaw", C.c_float), ("position", C.c_float * 3), ("fov_y", C.c_float),
+                ("near_clip", C.c_float), ("far_clip", C.c_float), ("target", C.c_float * 3), ("use_target", C.c_uint32)]
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("host layer %s is missing: build it with `make -C pathtracer_amd/host`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, fp, up = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.pth_mesh_load.restype = vp
+    L.pth_mesh_load.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.pth_mesh_free.argtypes = [vp]
+    L.pth_mesh_free.restype = None
+    L.pth_mesh_counts.argtypes = [vp] + [up] * 5
+    L.pth_mesh_counts.restype = None
+    L.pth_mesh_tables.argtypes = [vp, fp, fp, up, up, up, fp, fp]
+    L.pth_mesh_submesh_name.argtypes = [vp, C.c_uint32]
+    L.pth_mesh_submesh_name.restype = C.c_char_p
+    L.pth_mesh_texture_uri.argtypes = [vp, C.c_uint32]
+    L.pth_mesh_texture_uri.restype = C.c_char_p
+    L.pth_mesh_set_texture.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
+    L.pth_mesh_set_material.argtypes = [vp, C.c_uint32, fp]
+    L.pth_camera_matrices.argtypes = [C.POINTER(CameraSpec), C.c_uint32, C.c_uint32, fp]
+    L.pth_camera_matrices.restype = None
+    L.pth_layer_create.restype = vp
+    L.pth_layer_create.argtypes = [C.c_int, vp, fp, C.POINTER(CameraSpec), C.c_char_p, C.c_size_t]
+    L.pth_layer_destroy.argtypes = [vp]
+    L.pth_layer_destroy.restype = None
+    L.pth_layer_set_viewport.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.pth_layer_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.pth_layer_set_accumulate.argtypes = [vp, C.c_int]
+    L.pth_layer_set_camera_position.argtypes = [vp, fp]
+    for n in ("pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render"):
+        getattr(L, n).argtypes = [vp]
+    L.pth_layer_frame_index.argtypes = [vp]
+    L.pth_layer_frame_index.restype = C.c_uint32
+    L.pth_layer_read_image.argtypes = [vp, fp]
+    L.pth_layer_read_accum.argtypes = [vp, fp]
+    L.pth_layer_ray_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.pth_layer_last_error.argtypes = [vp]
+    L.pth_layer_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def camera_spec(position=(0, 0, 1), pitch=0.0, yaw=0.0, target=None, fov_y=45.0, near=0.1, far=1000.0):
+    s = CameraSpec()
+    s.pitch, s.yaw = pitch, yaw
+    s.position[:] = position
+    s.fov_y, s.near_clip, s.far_clip = fov_y, near, far
+    if target is not None:
+        s.target[:] = target
+        s.use_target = 1
+    return s
+
+
+def camera_matrices(spec, width, height):
+    out = np.empty(80, np.float32)
+    load_library().pth_camera_matrices(C.byref(spec), width, height, _fp(out))
+    return out
+
+
+class MeshSource:
+    """MeshSource(path): glTF 2.0 import by the C++ host layer."""
+
+    def __init__(self, path):
+        self.L = load_library()
+        err = C.create_string_buffer(512)
+        self.h = self.L.pth_mesh_load(path.encode(), err, len(err))
+        if not self.h:
+            raise RuntimeError("MeshSource(%s): %s" % (path, err.value.decode()))
+        self.path = path
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.pth_mesh_free(self.h)
+            self.h = None
+
+    def counts(self):
+        v = [C.c_uint32() for _ in range(5)]
+        self.L.pth_mesh_counts(self.h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def texture_uris(self):
+        return [self.L.pth_mesh_texture_uri(self.h, i).decode() for i in range(self.counts()[4])]
+
+    def set_texture(self, i, rgba8):
+        t = np.ascontiguousarray(rgba8, np.uint8)
+        assert self.L.pth_mesh_set_texture(self.h, i, t.shape[1], t.shape[0], t.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+
+    def set_material(self, i, words):
+        m = np.ascontiguousarray(words, np.float32)
+        assert m.size == 22 and self.L.pth_mesh_set_material(self.h, i, _fp(m)) == 0
+
+    def scene_data(self, layer_transform=None):
+        """The tables in pt_scene_desc layout; layer_transform is a 4x4 (row-major numpy) matrix."""
+        nv, ni, ns, nm, nt = self.counts()
+        vertices = np.empty((nv, 12), np.float32)
+        indices = np.empty(ni, np.uint32)
+        submeshes = np.empty((ns, 4), np.uint32)
+        counts = np.empty(ns, np.uint32)
+        xforms = np.empty((ns, 12), np.float32)
+        materials = np.empty((nm, 22), np.float32)
+        lt = None
+        if layer_transform is not None:
+            lt = np.ascontiguousarray(np.asarray(layer_transform, np.float32).T.reshape(-1))   # column-major
+        up = C.POINTER(C.c_uint32)
+        self.L.pth_mesh_tables(self.h, None if lt is None else _fp(lt), _fp(vertices), indices.ctypes.data_as(up),
+                               submeshes.ctypes.data_as(up), counts.ctypes.data_as(up), _fp(xforms), _fp(materials))
+        names = [self.L.pth_mesh_submesh_name(self.h, i).decode() for i in range(ns)]
+        return SceneData(vertices, indices, submeshes, counts, xforms, materials, names=names)
+
+
+class RayTracingLayer:
+    """Headless counterpart of the reference's layer: OnUpdate / OnRender with its FrameIndex rules."""
+
+    def __init__(self, mesh: MeshSource, transform=None, camera=None, device=0):
+        self.L = load_library()
+        self.mesh = mesh
+        t = np.eye(4, dtype=np.float32) if transform is None else np.asarray(transform, np.float32)
+        tc = np.ascontiguousarray(t.T.reshape(-1))
+        err = C.create_string_buffer(512)
+        cam = camera if camera is not None else camera_spec()
+        self.h = self.L.pth_layer_create(device, mesh.h, _fp(tc), C.byref(cam), err, len(err))
+        if not self.h:
+            raise RuntimeError("RayTracingLayer: " + err.value.decode())
+        self.width = self.height = 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pth_layer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc:
+            raise RuntimeError(self.L.pth_layer_last_error(self.h).decode())
+
+    def SetViewportSize(self, w, h):
+        self._check(self.L.pth_layer_set_viewport(self.h, w, h))
+        self.width, self.height = w, h
+
+    def SetParams(self, p: Params):
+        self._check(self.L.pth_layer_set_params(self.h, C.byref(p)))
+
+    def SetAccumulate(self, on):
+        self._check(self.L.pth_layer_set_accumulate(self.h, int(on)))
+
+    def SetCameraPosition(self, xyz):
+        p = np.asarray(xyz, np.float32)
+        self._check(self.L.pth_layer_set_camera_position(self.h, _fp(p)))
+
+    def MaterialsChanged(self):
+        self._check(self.L.pth_layer_materials_changed(self.h))
+
+    def OnUpdate(self):
+        self._check(self.L.pth_layer_on_update(self.h))
+
+    def OnRender(self):
+        self._check(self.L.pth_layer_on_render(self.h))
+
+    @property
+    def FrameIndex(self):
+        return self.L.pth_layer_frame_index(self.h)
+
+    def ReadImage(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self.L.pth_layer_read_image(self.h, _fp(out)))
+        return out
+
+    def ReadAccumulation(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self.L.pth_layer_read_accum(self.h, _fp(out)))
+        return out
+
+    def RayCount(self):
+        v = C.c_uint64()
+        self._check(self.L.pth_layer_ray_count(self.h, C.byref(v)))
+        return v.value

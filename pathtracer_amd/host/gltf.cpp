@@ -1,0 +1,315 @@
+// MeshSource: glTF 2.0 import into the tables the ray-tracing path reads.
+//
+// The reference loads its scenes with MeshSource(path) from its engine submodule
+// (PathTracer/src/RayTracingLayer.cpp:27-32), whose source is not in the checkout; what the import
+// must produce is fixed by the shaders instead: one shared vertex buffer of 48-byte vertices
+// (ClosestHit.glsl:56-81), one uint32 index buffer, one submesh per drawn primitive with its vertex
+// and index offsets and material index (ClosestHit.glsl:147-156), and 88-byte material records
+// (ClosestHit.glsl:113-142).  Conventions where the engine is unknown: scene nodes are walked depth
+// first in file order; glTF defaults for missing factors (base colour 1, metallic 1, roughness 1,
+// emissive 0, emissive strength 1); KHR_materials_emissive_strength and KHR_materials_ior are read,
+// ior defaults to 1.5 (the value Miss.glsl:28 uses), the other Disney parameters to 0; a missing
+// tangent becomes (1,0,0,1); texture indices are glTF image indices.
+#include "host.h"
+#include "json.h"
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace ptamd {
+
+namespace {
+
+std::string read_file(const std::string& path, bool binary)
+{
+    std::ifstream f(path, binary ? std::ios::binary : std::ios::in);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+std::string base64_decode(const std::string& s, size_t start)
+{
+    static int8_t table[256];
+    static bool init = false;
+    if (!init) {
+        std::memset(table, -1, sizeof(table));
+        const char* a = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+        for (int i = 0; i < 64; i++) table[(unsigned char)a[i]] = (int8_t)i;
+        init = true;
+    }
+    std::string out;
+    out.reserve((s.size() - start) * 3 / 4);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = start; i < s.size(); i++) {
+        int8_t v = table[(unsigned char)s[i]];
+        if (v < 0) continue;   // padding, whitespace
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            out += (char)((acc >> bits) & 0xFF);
+        }
+    }
+    return out;
+}
+
+struct Mat4d {
+    double m[4][4];   // m[row][col]
+    static Mat4d identity()
+    {
+        Mat4d r{};
+        for (int i = 0; i < 4; i++) r.m[i][i] = 1.0;
+        return r;
+    }
+    Mat4d operator*(const Mat4d& b) const
+    {
+        Mat4d r{};
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                double s = 0.0;
+                for (int k = 0; k < 4; k++) s += m[i][k] * b.m[k][j];
+                r.m[i][j] = s;
+            }
+        return r;
+    }
+};
+
+Mat4d node_local(const Json& node)
+{
+    Mat4d r = Mat4d::identity();
+    if (const Json* mj = node.find("matrix")) {
+        for (int c = 0; c < 4; c++)
+            for (int row = 0; row < 4; row++) r.m[row][c] = mj->at(c * 4 + row).num;
+        return r;
+    }
+    double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
+    if (const Json* j = node.find("translation")) for (int i = 0; i < 3; i++) t[i] = j->at(i).num;
+    if (const Json* j = node.find("rotation")) for (int i = 0; i < 4; i++) q[i] = j->at(i).num;
+    if (const Json* j = node.find("scale")) for (int i = 0; i < 3; i++) s[i] = j->at(i).num;
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double rot[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                        {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                        {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) r.m[i][j] = rot[i][j] * s[j];
+        r.m[i][3] = t[i];
+    }
+    return r;
+}
+
+struct Accessor {
+    const uint8_t* base = nullptr;
+    size_t count = 0, stride = 0;
+    int componentType = 0, ncomp = 0;
+    bool normalized = false;
+};
+
+size_t comp_size(int t)
+{
+    switch (t) {
+    case 5120: case 5121: return 1;
+    case 5122: case 5123: return 2;
+    case 5125: case 5126: return 4;
+    }
+    throw std::runtime_error("gltf: unknown component type " + std::to_string(t));
+}
+
+int num_comp(const std::string& t)
+{
+    if (t == "SCALAR") return 1;
+    if (t == "VEC2") return 2;
+    if (t == "VEC3") return 3;
+    if (t == "VEC4") return 4;
+    if (t == "MAT4") return 16;
+    throw std::runtime_error("gltf: unsupported accessor type " + t);
+}
+
+double read_comp(const Accessor& a, size_t i, int c)
+{
+    const uint8_t* p = a.base + i * a.stride + (size_t)c * comp_size(a.componentType);
+    switch (a.componentType) {
+    case 5126: { float f; std::memcpy(&f, p, 4); return f; }
+    case 5125: { uint32_t v; std::memcpy(&v, p, 4); return v; }
+    case 5123: { uint16_t v; std::memcpy(&v, p, 2); return a.normalized ? v / 65535.0 : v; }
+    case 5122: { int16_t v; std::memcpy(&v, p, 2); return a.normalized ? std::fmax(v / 32767.0, -1.0) : v; }
+    case 5121: { uint8_t v = *p; return a.normalized ? v / 255.0 : v; }
+    case 5120: { int8_t v; std::memcpy(&v, p, 1); return a.normalized ? std::fmax(v / 127.0, -1.0) : v; }
+    }
+    return 0.0;
+}
+
+} // namespace
+
+MeshSource::MeshSource(const std::string& path) : m_Path(path)
+{
+    std::string text = read_file(path, false);
+    Json g = JsonParser(text).parse();
+    std::string dir;
+    size_t slash = path.find_last_of("/\\");
+    if (slash != std::string::npos) dir = path.substr(0, slash + 1);
+
+    std::vector<std::string> buffers;
+    if (const Json* bj = g.find("buffers"))
+        for (const Json& b : bj->arr) {
+            std::string uri = b.gets("uri", "");
+            if (uri.rfind("data:", 0) == 0) {
+                size_t comma = uri.find(',');
+                if (comma == std::string::npos) throw std::runtime_error("gltf: malformed data uri");
+                buffers.push_back(base64_decode(uri, comma + 1));
+            } else {
+                buffers.push_back(read_file(dir + uri, true));
+            }
+            if (buffers.back().size() < (size_t)b.geti("byteLength", 0))
+                throw std::runtime_error("gltf: buffer '" + uri.substr(0, 40) + "' is shorter than its byteLength");
+        }
+
+    auto accessor = [&](int64_t idx) {
+        const Json& a = g.at("accessors").at((size_t)idx);
+        if (a.find("sparse")) throw std::runtime_error("gltf: sparse accessors are not supported");
+        const Json& bv = g.at("bufferViews").at((size_t)a.geti("bufferView", -1));
+        Accessor r;
+        r.componentType = (int)a.geti("componentType", 0);
+        r.ncomp = num_comp(a.gets("type", ""));
+        r.count = (size_t)a.geti("count", 0);
+        const Json* nj = a.find("normalized");
+        r.normalized = nj && nj->is(Json::Bool) && nj->b;
+        size_t elem = comp_size(r.componentType) * (size_t)r.ncomp;
+        r.stride = (size_t)bv.geti("byteStride", 0);
+        if (r.stride == 0) r.stride = elem;
+        size_t off = (size_t)bv.geti("byteOffset", 0) + (size_t)a.geti("byteOffset", 0);
+        const std::string& buf = buffers.at((size_t)bv.geti("buffer", 0));
+        if (r.count && off + (r.count - 1) * r.stride + elem > buf.size()) throw std::runtime_error("gltf: accessor exceeds its buffer");
+        r.base = reinterpret_cast<const uint8_t*>(buf.data()) + off;
+        return r;
+    };
+
+    if (const Json* ij = g.find("images"))
+        for (const Json& im : ij->arr) {
+            TextureData t;
+            t.Uri = im.gets("uri", "");
+            m_Textures.push_back(std::move(t));
+        }
+    auto image_of = [&](const Json* ref) -> int32_t {
+        if (!ref) return -1;
+        int64_t ti = ref->geti("index", -1);
+        const Json* tj = g.find("textures");
+        if (ti < 0 || !tj || (size_t)ti >= tj->size()) return -1;
+        return (int32_t)tj->at((size_t)ti).geti("source", -1);
+    };
+
+    if (const Json* mj = g.find("materials"))
+        for (const Json& m : mj->arr) {
+            MaterialData d{};
+            d.AlbedoValue[0] = d.AlbedoValue[1] = d.AlbedoValue[2] = 1.0f;
+            d.MetallicValue = 1.0f;
+            d.RoughnessValue = 1.0f;
+            d.EmissiveStrength = 1.0f;
+            d.AlbedoMapIndex = d.MetallicRoughnessMapIndex = d.NormalMapIndex = -1;
+            d.ior = 1.5f;
+            if (const Json* pbr = m.find("pbrMetallicRoughness")) {
+                if (const Json* c = pbr->find("baseColorFactor")) for (int i = 0; i < 3; i++) d.AlbedoValue[i] = (float)c->at(i).num;
+                d.MetallicValue = (float)pbr->get("metallicFactor", 1.0);
+                d.RoughnessValue = (float)pbr->get("roughnessFactor", 1.0);
+                d.AlbedoMapIndex = image_of(pbr->find("baseColorTexture"));
+                d.MetallicRoughnessMapIndex = image_of(pbr->find("metallicRoughnessTexture"));
+            }
+            if (const Json* e = m.find("emissiveFactor")) for (int i = 0; i < 3; i++) d.EmissiveValue[i] = (float)e->at(i).num;
+            d.NormalMapIndex = image_of(m.find("normalTexture"));
+            d.UseNormalMap = 0;
+            if (const Json* ext = m.find("extensions")) {
+                if (const Json* es = ext->find("KHR_materials_emissive_strength")) d.EmissiveStrength = (float)es->get("emissiveStrength", 1.0);
+                if (const Json* io = ext->find("KHR_materials_ior")) d.ior = (float)io->get("ior", 1.5);
+            }
+            m_Materials.push_back(d);
+        }
+    int32_t default_material = -1;
+
+    struct Walker {
+        MeshSource& self;
+        const Json& g;
+        decltype(accessor)& acc;
+        int32_t& default_material;
+        void walk(size_t ni, const Mat4d& parent)
+        {
+            const Json& node = g.at("nodes").at(ni);
+            Mat4d world = parent * node_local(node);
+            if (const Json* mi = node.find("mesh")) {
+                const Json& mesh = g.at("meshes").at((size_t)mi->num);
+                const Json& prims = mesh.at("primitives");
+                for (size_t pi = 0; pi < prims.size(); pi++) {
+                    const Json& prim = prims.at(pi);
+                    if (prim.geti("mode", 4) != 4) continue;
+                    const Json& at = prim.at("attributes");
+                    Accessor pos = acc(at.at("POSITION").num);
+                    if (pos.ncomp != 3) throw std::runtime_error("gltf: POSITION must be VEC3");
+                    size_t n = pos.count;
+                    Accessor uv{}, nrm{}, tan{};
+                    if (const Json* j = at.find("TEXCOORD_0")) uv = acc((int64_t)j->num);
+                    if (const Json* j = at.find("NORMAL")) nrm = acc((int64_t)j->num);
+                    if (const Json* j = at.find("TANGENT")) tan = acc((int64_t)j->num);
+                    SubMesh sm;
+                    sm.VertexOffset = (uint32_t)self.m_Vertices.size();
+                    sm.IndexOffset = (uint32_t)self.m_Indices.size();
+                    sm.VertexCount = (uint32_t)n;
+                    for (size_t i = 0; i < n; i++) {
+                        Vertex v{};
+                        for (int c = 0; c < 3; c++) v.Position[c] = (float)read_comp(pos, i, c);
+                        if (uv.base && i < uv.count) for (int c = 0; c < 2; c++) v.TextureCoords[c] = (float)read_comp(uv, i, c);
+                        if (nrm.base && i < nrm.count) for (int c = 0; c < 3; c++) v.Normal[c] = (float)read_comp(nrm, i, c);
+                        if (tan.base && i < tan.count) for (int c = 0; c < 4; c++) v.Tangent[c] = (float)read_comp(tan, i, c);
+                        else { v.Tangent[0] = 1.0f; v.Tangent[3] = 1.0f; }
+                        self.m_Vertices.push_back(v);
+                    }
+                    size_t ni_count;
+                    if (const Json* ij = prim.find("indices")) {
+                        Accessor ia = acc((int64_t)ij->num);
+                        ni_count = ia.count;
+                        for (size_t i = 0; i < ia.count; i++) {
+                            double v = read_comp(ia, i, 0);
+                            if (v < 0 || v >= (double)n) throw std::runtime_error("gltf: index out of range");
+                            self.m_Indices.push_back((uint32_t)v);
+                        }
+                    } else {
+                        ni_count = n;
+                        for (size_t i = 0; i < n; i++) self.m_Indices.push_back((uint32_t)i);
+                    }
+                    sm.IndexCount = (uint32_t)(ni_count - ni_count % 3);
+                    int64_t mat = prim.geti("material", -1);
+                    if (mat < 0 || (size_t)mat >= self.m_Materials.size()) {
+                        if (default_material < 0) {
+                            MaterialData d{};
+                            d.AlbedoValue[0] = d.AlbedoValue[1] = d.AlbedoValue[2] = 1.0f;
+                            d.MetallicValue = 0.0f;
+                            d.RoughnessValue = 1.0f;
+                            d.EmissiveStrength = 1.0f;
+                            d.AlbedoMapIndex = d.MetallicRoughnessMapIndex = d.NormalMapIndex = -1;
+                            d.ior = 1.5f;
+                            default_material = (int32_t)self.m_Materials.size();
+                            self.m_Materials.push_back(d);
+                        }
+                        mat = default_material;
+                    }
+                    sm.MaterialIndex = (uint32_t)mat;
+                    std::string name = node.gets("name", mesh.gets("name", "node" + std::to_string(ni)));
+                    sm.Name = pi == 0 ? name : name + "." + std::to_string(pi);
+                    for (int c = 0; c < 4; c++)
+                        for (int r = 0; r < 4; r++) sm.WorldTransform.m[c * 4 + r] = (float)world.m[r][c];
+                    self.m_SubMeshes.push_back(sm);
+                }
+            }
+            if (const Json* ch = node.find("children"))
+                for (const Json& c : ch->arr) walk((size_t)c.num, world);
+        }
+    } walker{*this, g, accessor, default_material};
+
+    size_t scene = (size_t)g.geti("scene", 0);
+    const Json& roots = g.at("scenes").at(scene).at("nodes");
+    for (const Json& r : roots.arr) walker.walk((size_t)r.num, Mat4d::identity());
+    if (m_SubMeshes.empty()) throw std::runtime_error("gltf: no triangle primitives in " + path);
+}
+
+} // namespace ptamd

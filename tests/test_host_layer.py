@@ -1,0 +1,167 @@
+"""The C++ host layer: glTF import against the independent Python reader, camera matrices, and
+(on a GPU) the reference's frame sequencing through RayTracingLayer."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import camera, host
+from pathtracer_amd.scene import Params
+from tests import gltf_py
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_MODELS = "/root/reference/PathTracer/assets/models"
+have_ref = os.path.exists(REF_MODELS)
+
+
+def test_host_library_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "pathtracer_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(pth_[a-z_0-9]+)\s*\(", text)))
+    lib = host.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert declared == sorted(host.EXPORTS)
+
+
+def write_gltf(tmp_path):
+    """A two-node glTF with a child transform, uint16 indices, an external .bin and a default material."""
+    import json
+    import struct
+    pos = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0)]
+    nrm = [(0, 0, 1)] * 4
+    idx = [0, 1, 2, 2, 1, 3]
+    blob = b"".join(struct.pack("<3f", *p) for p in pos) + b"".join(struct.pack("<3f", *n) for n in nrm) + struct.pack("<6H", *idx)
+    (tmp_path / "quad.bin").write_bytes(blob)
+    g = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+        "nodes": [{"name": "root", "translation": [1, 2, 3], "scale": [2, 2, 2], "children": [1], "mesh": 0},
+                  {"name": "kid", "rotation": [0, 0.7071068, 0, 0.7071068], "mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1}, "indices": 2, "material": 0},
+                                   {"attributes": {"POSITION": 0, "NORMAL": 1}, "indices": 2}]}],
+        "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1], "metallicFactor": 0.25, "roughnessFactor": 0.5},
+                       "emissiveFactor": [1, 0.5, 0.25],
+                       "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 3.0}, "KHR_materials_ior": {"ior": 1.33}}}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 2, "componentType": 5123, "count": 6, "type": "SCALAR"}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 48}, {"buffer": 0, "byteOffset": 48, "byteLength": 48},
+                        {"buffer": 0, "byteOffset": 96, "byteLength": 12}],
+        "buffers": [{"uri": "quad.bin", "byteLength": 108}],
+    }
+    path = tmp_path / "quad.gltf"
+    path.write_text(json.dumps(g))
+    return str(path)
+
+
+def assert_same_scene(a, b):
+    assert np.array_equal(a.vertices, b.vertices)
+    assert np.array_equal(a.indices, b.indices)
+    assert np.array_equal(a.submeshes, b.submeshes)
+    assert np.array_equal(a.index_counts, b.index_counts)
+    assert np.allclose(a.xforms, b.xforms, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(a.materials.view(np.uint32), b.materials.view(np.uint32))
+    assert a.names == b.names
+
+
+def test_gltf_import_synthetic(tmp_path):
+    path = write_gltf(tmp_path)
+    layer = np.diag([0.5, 0.5, 0.5, 1.0])
+    got = host.MeshSource(path).scene_data(layer)
+    want = gltf_py.load_gltf(path, layer)
+    assert_same_scene(got, want)
+    assert len(got.submeshes) == 4 and got.names == ["root", "root.1", "kid", "kid.1"]
+    assert got.materials.shape[0] == 2                      # one declared + the default for the material-less primitive
+    assert np.allclose(got.materials[0, :9], [0.2, 0.4, 0.6, 0.25, 0.5, 1, 0.5, 0.25, 3.0])
+    assert np.isclose(got.materials[0, 21], 1.33) and np.isclose(got.materials[1, 21], 1.5)
+    # child: parent TRS * 90 degree yaw, then the layer scale
+    assert np.allclose(got.xforms[0].reshape(3, 4), [[1, 0, 0, 0.5], [0, 1, 0, 1], [0, 0, 1, 1.5]], atol=1e-6)
+    assert np.allclose(got.xforms[2].reshape(3, 4), [[0, 0, 1, 0.5], [0, 1, 0, 1], [-1, 0, 0, 1.5]], atol=1e-6)
+
+
+def test_gltf_import_errors(tmp_path):
+    with pytest.raises(RuntimeError):
+        host.MeshSource(str(tmp_path / "missing.gltf"))
+    bad = tmp_path / "bad.gltf"
+    bad.write_text("{ not json")
+    with pytest.raises(RuntimeError):
+        host.MeshSource(str(bad))
+
+
+@pytest.mark.skipif(not have_ref, reason="reference assets are only mounted in the authoring container")
+@pytest.mark.parametrize("rel", ["CornellBox.gltf", "Cube.gltf", "Suzanne/glTF/Suzanne.gltf"])
+def test_gltf_import_reference_assets(rel):
+    path = os.path.join(REF_MODELS, rel)
+    layer = np.diag([0.1, 0.1, 0.1, 1.0])
+    src = host.MeshSource(path)
+    assert_same_scene(src.scene_data(layer), gltf_py.load_gltf(path, layer))
+
+
+@pytest.mark.skipif(not have_ref, reason="reference assets are only mounted in the authoring container")
+def test_cornell_fixture_is_the_host_loader_output(cornell):
+    got = host.MeshSource(os.path.join(REF_MODELS, "CornellBox.gltf")).scene_data(np.diag([0.1, 0.1, 0.1, 1.0]))
+    assert_same_scene(got, cornell)
+    assert got.num_triangles == 63978 and len(got.submeshes) == 11 and len(got.materials) == 5
+
+
+def test_camera_matrices_match_the_python_convention():
+    for (w, h) in [(512, 512), (1920, 1080)]:
+        spec = host.camera_spec(position=(-0.025, 0.26, 0.75), target=(-0.025, 0.26, -0.3), fov_y=45.0, near=0.01, far=100.0)
+        got = host.camera_matrices(spec, w, h).reshape(5, 16)
+        want = camera.cornell_camera(w, h).reshape(5, 16)
+        for k in range(5):
+            scale = np.abs(want[k]).max()
+            assert np.allclose(got[k], want[k], rtol=1e-5, atol=2e-6 * scale), k
+    spec = host.camera_spec(position=(-12.5, 6.7, -1.85), pitch=0.208, yaw=1.731, fov_y=60.0, near=0.05, far=200.0)
+    got = host.camera_matrices(spec, 1920, 1080).reshape(5, 16)
+    want = camera.camera_buffer(camera.from_pitch_yaw((-12.5, 6.7, -1.85), 0.208, 1.731), camera.perspective(60.0, 1920 / 1080, 0.05, 200.0)).reshape(5, 16)
+    assert np.allclose(got[3], want[3], rtol=1e-5, atol=1e-5) and np.allclose(got[4], want[4], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_layer_frame_sequencing(tmp_path):
+    """RayTracingLayer.cpp:283,356-357,390-397,620: FrameIndex starts at 1, ++ per render, resets on resize,
+    camera move, material change and when accumulation is off."""
+    path = write_gltf(tmp_path)
+    src = host.MeshSource(path)
+    cam = host.camera_spec(position=(2.0, 3.0, 8.0), target=(2.0, 3.0, 3.0))
+    layer = host.RayTracingLayer(src, camera=cam)
+    layer.SetParams(Params.reference(spp_per_frame=2, max_bounces=3))
+    layer.SetViewportSize(40, 24)
+    assert layer.FrameIndex == 1
+    for expect in (1, 2, 3):
+        layer.OnUpdate()
+        if expect == 1:
+            assert layer.FrameIndex == 1         # the first Update sees the initial pose as "moved"
+        layer.OnRender()
+        assert layer.FrameIndex == expect + 1
+    acc = layer.ReadAccumulation()
+    assert (acc[..., 3] == 4).all()              # frames 2 and 3 accumulated 2 samples each; frame 1 only cleared
+    img = layer.ReadImage()
+    assert img[..., :3].max() > 0
+    n = layer.RayCount()
+    assert 40 * 24 * 2 * 3 <= n <= 40 * 24 * 2 * 3 * 3
+    layer.SetCameraPosition((2.0, 3.0, 9.0))
+    layer.OnUpdate()
+    assert layer.FrameIndex == 1
+    layer.OnRender()
+    layer.SetViewportSize(32, 16)
+    layer.OnUpdate()
+    layer.OnRender()
+    assert layer.FrameIndex == 2 and not layer.ReadAccumulation().any()
+    layer.OnUpdate(); layer.OnRender()
+    words = np.zeros(22, np.float32)
+    words[0:3] = 0.9
+    words[4] = 0.5
+    words[8] = 1.0
+    words.view(np.int32)[10:13] = -1
+    words[21] = 1.5
+    src.set_material(0, words)
+    layer.MaterialsChanged()
+    assert layer.FrameIndex == 1
+    layer.SetAccumulate(False)
+    layer.OnUpdate(); layer.OnRender()
+    layer.OnUpdate()
+    assert layer.FrameIndex == 1
+    layer.close()
