@@ -39,12 +39,14 @@ def host_threads():
     return max(1, min(16, n))
 
 
-def make_workload(name, width, height):
+def make_workload(name, width, height, detail=1.0):
     from pathtracer_amd import camera, procedural
     from pathtracer_amd.scene import SceneData
     if name == "sponza_class":
-        return procedural.sponza_class(), procedural.sponza_camera(width, height), \
-            "procedural Sponza-class atrium (273536 tris, 103 submeshes, 25 full-Disney materials; Sponza.bin is absent from the reference)"
+        sc = procedural.sponza_class(detail=detail)
+        return sc, procedural.sponza_camera(width, height), \
+            "procedural Sponza-class atrium (%d tris, %d submeshes, 25 full-Disney materials; Sponza.bin is absent from the reference)" % (
+                sc.num_triangles, len(sc.submeshes))
     if name == "bistro_class":
         return procedural.bistro_class(), procedural.bistro_camera(width, height), "procedural Bistro-class street (~3M tris)"
     if name == "cornell":
@@ -64,6 +66,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--build-flags", type=int, default=0)
+    ap.add_argument("--detail", type=float, default=1.0, help="tessellation scale of the procedural scenes (1 = the benchmark scene)")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,7 +90,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    scene, cam, workload_text = make_workload(args.workload, args.width, args.height)
+    scene, cam, workload_text = make_workload(args.workload, args.width, args.height, args.detail)
     params = Params.reference(spp_per_frame=1, max_bounces=args.bounces)
     b = Backend(local_rank)
     b.scene_upload(scene)

@@ -47,9 +47,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("HIP backend %s is missing: build it with `make -C pathtracer_amd/csrc`" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("PATHTRACER_AMD_LIB", LIB_PATH)     # override: A/B runs of differently tuned builds
+    if not os.path.exists(path):
+        raise ImportError("HIP backend %s is missing: build it with `make -C pathtracer_amd/csrc`" % path)
+    lib = C.CDLL(path)
     vp, fp, up = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     lib.pt_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.pt_destroy.argtypes = [vp]

@@ -2,6 +2,8 @@
 // reference's descriptor-set contents (PathTracer/src/RayTracingLayer.cpp:248-263), image management
 // and read-back.  No exception crosses the boundary; every entry point returns a status code.
 #include "pt_context.h"
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -81,10 +83,13 @@ static int finish_timing(pt_ctx* ctx)
     PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[2 + 2 * R]));
     t.total_ms = ms;
     if (ctx->profiling == 2) {
-        unsigned long long hs[2] = {0, 0};
-        PT_HIP(ctx, hipMemcpy(hs, ctx->d_stats, 16, hipMemcpyDeviceToHost));
+        unsigned long long hs[8] = {0};
+        PT_HIP(ctx, hipMemcpy(hs, ctx->d_stats, 64, hipMemcpyDeviceToHost));
         t.nodes_visited = hs[0];
         t.tris_tested = hs[1];
+        if (getenv("PT_WAVE_STATS"))
+            fprintf(stderr, "wave stats: node phases %llu (lanes %llu, %.1f/64), leaf phases %llu (lanes %llu, %.1f/64), refills %llu\n",
+                    hs[3], hs[4], hs[3] ? (double)hs[4] / hs[3] : 0.0, hs[5], hs[6], hs[5] ? (double)hs[6] / hs[5] : 0.0, hs[7]);
     }
     ctx->timing = t;
     return PT_OK;
@@ -116,10 +121,10 @@ int pt_create(int device_ordinal, pt_ctx** out)
     pt_default_params(&ctx->params);
     hipError_t es = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     hipError_t e1 = hipMalloc((void**)&ctx->d_total_rays, 8);
-    hipError_t e2 = hipMalloc((void**)&ctx->d_stats, 16);
+    hipError_t e2 = hipMalloc((void**)&ctx->d_stats, 64);
     if (es != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) { pt_destroy(ctx); return set_error(nullptr, PT_ERR_HIP, "context allocation failed"); }
     (void)hipMemset(ctx->d_total_rays, 0, 8);
-    (void)hipMemset(ctx->d_stats, 0, 16);
+    (void)hipMemset(ctx->d_stats, 0, 64);
     *out = ctx;
     return PT_OK;
 }
@@ -343,7 +348,7 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
     if (rounds + 1 > ctx->counts_cap) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         (void)dev_free(ctx->d_counts);
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (size_t)(rounds + 1) * PT_SHARDS * sizeof(uint32_t)));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (size_t)2 * (rounds + 1) * PT_SHARDS * sizeof(uint32_t)));
         ctx->counts_cap = rounds + 1;
     }
     if (ctx->timing_pending) {   // a profiled frame is still in flight: collect it before its events are reused

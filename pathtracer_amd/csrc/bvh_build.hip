@@ -6,9 +6,14 @@
 //   1. k_world_tris   every submesh triangle -> world space (object-to-world 3x4), its box, scene bounds
 //   2. k_morton       63-bit Morton code of the box centre
 //   3. radix sort     (rocPRIM via hipcub) of (code, triangle)
-//   4. k_karras       binary radix tree over the sorted codes (Karras 2012), duplicates split by index
-//   5. k_refit        bottom-up boxes and subtree triangle counts; the second child to arrive continues
-//   6. k_collapse     level by level: binary tree -> 4-wide nodes of 128 bytes, subtrees of <= 4 triangles
+//   4. binary hierarchy, one of
+//      a. agglomerative (default): parallel locally-ordered clustering -- every cluster looks PLOC_RADIUS
+//         places left and right in Morton order for the neighbour that gives the smallest merged box,
+//         mutual nearest neighbours merge, the cluster list is compacted with a prefix scan, repeat until
+//         one cluster is left (k_ploc_nearest, k_ploc_flags, scan, k_ploc_merge).  Near-SAH quality.
+//      b. PT_BUILD_LBVH: binary radix tree over the sorted codes (Karras 2012, k_karras) and bottom-up
+//         boxes with an arrival counter per node (k_refit).  Fastest build, about 1.6x the traversal cost.
+//   5. k_collapse     level by level: binary tree -> 4-wide nodes of 128 bytes, subtrees of <= 4 triangles
 //                     become leaves, triangles are written out in leaf order
 #include "pt_context.h"
 #include "pt_math.h"
@@ -192,6 +197,102 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals, const float4* 
     }
 }
 
+
+// ---- agglomerative build (parallel locally-ordered clustering) ------------------------------------
+static constexpr int PLOC_RADIUS = 16;
+static constexpr int PLOC_BLOCK = 256;
+
+__global__ void k_ploc_init(int n, const uint32_t* __restrict__ vals, const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                            uint32_t* __restrict__ cid, float4* __restrict__ b2lo, float4* __restrict__ b2hi)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t t = vals[j];
+    float4 lo = tlo[t], hi = thi[t];
+    lo.w = __uint_as_float(1u);
+    uint32_t node = (uint32_t)(n - 1 + j);
+    b2lo[node] = lo;
+    b2hi[node] = hi;
+    cid[j] = node;
+}
+
+// nearest neighbour (smallest surface area of the merged box) within PLOC_RADIUS places; ties -> lower index
+__global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_nearest(int nc, const uint32_t* __restrict__ cid, const float4* __restrict__ b2lo,
+                                                             const float4* __restrict__ b2hi, uint32_t* __restrict__ nearest)
+{
+    __shared__ float slo[PLOC_BLOCK + 2 * PLOC_RADIUS][3];
+    __shared__ float shi[PLOC_BLOCK + 2 * PLOC_RADIUS][3];
+    int base = blockIdx.x * PLOC_BLOCK - PLOC_RADIUS;
+    for (int k = threadIdx.x; k < PLOC_BLOCK + 2 * PLOC_RADIUS; k += PLOC_BLOCK) {
+        int g = base + k;
+        if (g >= 0 && g < nc) {
+            uint32_t id = cid[g];
+            float4 lo = b2lo[id], hi = b2hi[id];
+            slo[k][0] = lo.x; slo[k][1] = lo.y; slo[k][2] = lo.z;
+            shi[k][0] = hi.x; shi[k][1] = hi.y; shi[k][2] = hi.z;
+        }
+    }
+    __syncthreads();
+    int i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
+    if (i >= nc) return;
+    int li = threadIdx.x + PLOC_RADIUS;
+    float lx = slo[li][0], ly = slo[li][1], lz = slo[li][2], hx = shi[li][0], hy = shi[li][1], hz = shi[li][2];
+    float best = __builtin_inff();
+    int bestj = -1;
+    for (int dlt = -PLOC_RADIUS; dlt <= PLOC_RADIUS; dlt++) {
+        int j = i + dlt;
+        if (dlt == 0 || j < 0 || j >= nc) continue;
+        int lj = li + dlt;
+        float ex = fmaxf(hx, shi[lj][0]) - fminf(lx, slo[lj][0]);
+        float ey = fmaxf(hy, shi[lj][1]) - fminf(ly, slo[lj][1]);
+        float ez = fmaxf(hz, shi[lj][2]) - fminf(lz, slo[lj][2]);
+        float a = ex * ey + ey * ez + ez * ex;
+        if (a < best) { best = a; bestj = j; }
+    }
+    nearest[i] = (uint32_t)bestj;
+}
+
+// flags[i]: low word = 1 when cluster i survives (unmerged, or the lower index of a merging pair),
+//           high word = 1 when cluster i is the lower index of a merging pair (creates a node)
+__global__ void k_ploc_flags(int nc, const uint32_t* __restrict__ nearest, unsigned long long* __restrict__ flags)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    uint32_t j = nearest[i];
+    bool mutual = j != 0xFFFFFFFFu && nearest[j] == (uint32_t)i;
+    unsigned long long f = 1ull;
+    if (mutual) f = (uint32_t)i < j ? (1ull | (1ull << 32)) : 0ull;
+    flags[i] = f;
+}
+
+__global__ void k_ploc_merge(int nc, uint32_t next_id, const uint32_t* __restrict__ nearest, const unsigned long long* __restrict__ flags,
+                             const unsigned long long* __restrict__ scan, const uint32_t* __restrict__ cid_in, uint32_t* __restrict__ cid_out,
+                             uint2* __restrict__ children, float4* b2lo, float4* b2hi, uint32_t* __restrict__ totals)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    unsigned long long f = flags[i], sc = scan[i];
+    if (i == nc - 1) {
+        unsigned long long tot = sc + f;
+        totals[0] = (uint32_t)tot;          // clusters after this round
+        totals[1] = (uint32_t)(tot >> 32);  // nodes created
+    }
+    if (!(f & 1ull)) return;
+    uint32_t pos = (uint32_t)sc;
+    if (f >> 32) {
+        uint32_t a = cid_in[i], b = cid_in[nearest[i]];
+        uint32_t id = next_id + (uint32_t)(sc >> 32);
+        float4 alo = b2lo[a], ahi = b2hi[a], blo = b2lo[b], bhi = b2hi[b];
+        b2lo[id] = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z),
+                               __uint_as_float(__float_as_uint(alo.w) + __float_as_uint(blo.w)));
+        b2hi[id] = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.0f);
+        children[id] = make_uint2(a, b);
+        cid_out[pos] = id;
+    } else {
+        cid_out[pos] = cid_in[i];
+    }
+}
+
 __device__ __forceinline__ float box_area(float4 lo, float4 hi)
 {
     float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
@@ -251,7 +352,7 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
         if (cnt <= PT_LEAF_MAX) {
             nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
             // write the subtree's triangles in depth-first order
-            uint32_t stack[8];
+            uint32_t stack[16];
             int sp = 0;
             uint32_t w = tstart;
             stack[sp++] = c;
@@ -307,7 +408,6 @@ struct DevBuf {
 
 int build_accel(pt_ctx* ctx, uint32_t flags)
 {
-    (void)flags;
     hipStream_t st = ctx->stream;
     uint32_t n = ctx->num_tris;
     if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
@@ -364,10 +464,46 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
     PT_HIP(ctx, sort_tmp.alloc(tmp_bytes));
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
-    PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
-    PT_HIP(ctx, hipMemsetAsync(parent.p, 0xFF, 2 * (size_t)n * sizeof(uint32_t), st));
-    if (n > 1) k_karras<<<G, B, 0, st>>>((int)n, keys_sorted.p, children.p, parent.p);
-    k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, tlo.p, thi.p, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p);
+    uint32_t root_id = 0;   // binary-tree node ids: internal 0..n-2, leaf j -> (n-1)+j
+    if (flags & PT_BUILD_LBVH) {
+        PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
+        PT_HIP(ctx, hipMemsetAsync(parent.p, 0xFF, 2 * (size_t)n * sizeof(uint32_t), st));
+        if (n > 1) k_karras<<<G, B, 0, st>>>((int)n, keys_sorted.p, children.p, parent.p);
+        k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, tlo.p, thi.p, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p);
+    } else {
+        DevBuf<uint32_t> cid[2], nearest, totals;
+        DevBuf<unsigned long long> pflags, pscan;
+        DevBuf<char> scan_tmp;
+        PT_HIP(ctx, cid[0].alloc(n));
+        PT_HIP(ctx, cid[1].alloc(n));
+        PT_HIP(ctx, nearest.alloc(n));
+        PT_HIP(ctx, totals.alloc(2));
+        PT_HIP(ctx, pflags.alloc(n));
+        PT_HIP(ctx, pscan.alloc(n));
+        size_t scan_bytes = 0;
+        PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, pflags.p, pscan.p, (int)n, st));
+        PT_HIP(ctx, scan_tmp.alloc(scan_bytes));
+        k_ploc_init<<<G, B, 0, st>>>((int)n, vals_sorted.p, tlo.p, thi.p, cid[0].p, b2lo.p, b2hi.p);
+        uint32_t nc = n, next_id = 0;
+        int cur = 0, rounds = 0;
+        while (nc > 1) {
+            uint32_t g = (nc + PLOC_BLOCK - 1) / PLOC_BLOCK;
+            k_ploc_nearest<<<g, PLOC_BLOCK, 0, st>>>((int)nc, cid[cur].p, b2lo.p, b2hi.p, nearest.p);
+            k_ploc_flags<<<g, PLOC_BLOCK, 0, st>>>((int)nc, nearest.p, pflags.p);
+            PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, pflags.p, pscan.p, (int)nc, st));
+            k_ploc_merge<<<g, PLOC_BLOCK, 0, st>>>((int)nc, next_id, nearest.p, pflags.p, pscan.p, cid[cur].p, cid[cur ^ 1].p,
+                                                   children.p, b2lo.p, b2hi.p, totals.p);
+            uint32_t ht[2];
+            PT_HIP(ctx, hipMemcpyAsync(ht, totals.p, sizeof(ht), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            if (ht[1] == 0 || ht[0] != nc - ht[1]) return set_error(ctx, PT_ERR_INVALID, "hierarchy build: clustering made no progress");
+            nc = ht[0];
+            next_id += ht[1];
+            cur ^= 1;
+            if (++rounds > 4096) return set_error(ctx, PT_ERR_INVALID, "hierarchy build: clustering did not terminate");
+        }
+        root_id = n > 1 ? next_id - 1 : 0;   // the last node created is the root
+    }
 
     // padding of every child box: covers the rounding of the slab test and of the triangle test's t
     int hb[6];
@@ -384,8 +520,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     // collapse: counters[0] = nodes allocated, [1] = leaves, [2],[3] = frontier sizes (ping-pong)
     uint32_t init[4] = {1u, 0u, 0u, 0u};
     PT_HIP(ctx, hipMemcpyAsync(counters.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-    CollapseItem root{0u, 0u, 0u, 0u};
-    if (n == 1) root.node2 = 0u;   // the single leaf has id n-1 = 0
+    CollapseItem root{root_id, 0u, 0u, 0u};   // n == 1: the single leaf has id n-1 = 0
     PT_HIP(ctx, hipMemcpyAsync(fr[0].p, &root, sizeof(root), hipMemcpyHostToDevice, st));
     uint32_t nitems = 1, depth = 0;
     int cur = 0;

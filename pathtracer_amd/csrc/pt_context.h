@@ -49,10 +49,10 @@ struct pt_ctx {
     float4* d_stB = nullptr;
     float4* d_stC = nullptr;
     uint32_t shard_cap = 0;         // ray-queue slots per shard
-    uint32_t* d_counts = nullptr;   // PT_SHARDS per round, rounds + 1 rows
+    uint32_t* d_counts = nullptr;   // PT_SHARDS per round, rounds + 1 rows of queue sizes, then as many rows of fetch cursors
     uint32_t counts_cap = 0;
     unsigned long long* d_total_rays = nullptr;
-    unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested (debug intersect)
+    unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested, [2] fetch cursor of pt_debug_intersect
 
     pt_params params{};
     float camera[80];

@@ -1,10 +1,16 @@
-// Closest-hit traversal of the 4-wide hierarchy, one ray per lane.
+// Closest-hit traversal of the 4-wide hierarchy, one ray per lane, persistent waves.
 //
 // Replaces traceRayEXT (PathTracer/assets/shaders/RayTracing/RayGen.glsl:124), which the
 // reference leaves to the Vulkan driver and RT hardware.  Semantics: closest hit with
 // tmin < t < tmax, opaque, no culling; watertight Woop-style triangle test with a
 // double-precision fallback for zero edge functions; at equal t the smaller
 // (submesh, primitive) wins, so the answer does not depend on traversal order.
+//
+// Execution: a wave keeps 64 traversals in flight.  Rays differ widely in length, so a wave that
+// waited for its longest ray would idle most lanes; instead, whenever PT_REFILL_MIN lanes are free
+// the wave takes that many new rays from its queue with one atomic and carries on (dynamic ray
+// fetch).  Node steps and leaf steps are separate phases: lanes that reached a leaf wait until
+// enough lanes have one (or nobody has a node left), so the triangle code runs with fuller waves.
 //
 // Stack: the first PT_STACK_LDS entries of each lane live in LDS (one column per lane,
 // conflict free), deeper entries spill to per-lane scratch.  An entry carries the
@@ -17,7 +23,15 @@
 namespace ptd {
 
 #define PT_STACK_LDS 16
+#ifndef PT_STACK_OVF
 #define PT_STACK_OVF 80    // host refuses hierarchies whose depth could need more than LDS+OVF entries
+#endif
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 20   // free lanes that trigger a refill
+#endif
+#ifndef PT_LEAF_MIN
+#define PT_LEAF_MIN 16     // lanes holding a leaf that trigger the triangle phase while others still walk nodes
+#endif
 
 struct HitRec {
     float t, u, v;
@@ -81,105 +95,204 @@ PT_DEV bool tri_test(const RayPre& r, v3 o, v3 v0, v3 v1, v3 v2, float tmin, flo
     return true;
 }
 
-// lds_stack points at this lane's column: entry k is lds_stack[k * stride]
-template <bool STATS>
-PT_DEV HitRec traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris,
-                       v3 o, v3 d, float tmin, float tmax, uint2* lds_stack, int stride,
-                       uint32_t& stat_nodes, uint32_t& stat_tris)
-{
+// per-lane traversal state
+struct Trav {
+    v3 o;
+    float tmin, tmax;
+    RayPre rp;
+    float idx, idy, idz;           // 1 / direction (zero components replaced by +-1e-20)
+    float onx, ony, onz;           // -(o * idir) - slack : near planes
+    float ofx, ofy, ofz;           // -(o * idir) + slack : far planes
+    int nx, ny, nz;                // float4 index of the near plane arrays in a node (lo = 0..2, hi = 3..5)
     HitRec best;
-    best.t = tmax; best.u = 0.0f; best.v = 0.0f;
-    best.tri = 0xFFFFFFFFu; best.submesh = 0xFFFFFFFFu; best.prim = 0xFFFFFFFFu;
-    if (num_tris == 0) return best;
+    uint32_t cur;                  // node index, or leaf reference (bit 31)
+    int sp;
+};
 
-    RayPre rp = ray_precompute(d);
-
-    // slab test set-up: t = plane * idir + ood, near/far plane picked by the direction sign
-    float idx, idy, idz;
-    {
-        float cx = d.x, cy = d.y, cz = d.z;
-        if (gabs(cx) < 1e-20f) cx = (f2u(cx) >> 31) ? -1e-20f : 1e-20f;
-        if (gabs(cy) < 1e-20f) cy = (f2u(cy) >> 31) ? -1e-20f : 1e-20f;
-        if (gabs(cz) < 1e-20f) cz = (f2u(cz) >> 31) ? -1e-20f : 1e-20f;
-        idx = fdiv(1.0f, cx); idy = fdiv(1.0f, cy); idz = fdiv(1.0f, cz);
-    }
-    float oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
+PT_DEV void trav_init(Trav& s, v3 o, v3 d, float tmin, float tmax)
+{
+    s.o = o;
+    s.tmin = tmin;
+    s.tmax = tmax;
+    s.rp = ray_precompute(d);
+    float cx = d.x, cy = d.y, cz = d.z;
+    if (gabs(cx) < 1e-20f) cx = (f2u(cx) >> 31) ? -1e-20f : 1e-20f;
+    if (gabs(cy) < 1e-20f) cy = (f2u(cy) >> 31) ? -1e-20f : 1e-20f;
+    if (gabs(cz) < 1e-20f) cz = (f2u(cz) >> 31) ? -1e-20f : 1e-20f;
+    s.idx = fdiv(1.0f, cx); s.idy = fdiv(1.0f, cy); s.idz = fdiv(1.0f, cz);
+    float oix = o.x * s.idx, oiy = o.y * s.idy, oiz = o.z * s.idz;
     // rounding of o*idir moves the planes by at most |o*idir| * 2^-24; widen by 4x that
     float slack = fmaxf(fmaxf(gabs(oix), gabs(oiy)), gabs(oiz)) * 0x1p-22f;
-    float onx = -oix - slack, ony = -oiy - slack, onz = -oiz - slack;   // near planes
-    float ofx = -oix + slack, ofy = -oiy + slack, ofz = -oiz + slack;   // far planes
-    // float4 index of the near / far plane arrays inside a node (lo = 0..2, hi = 3..5)
-    const int nx = idx < 0.0f ? 3 : 0, ny = idy < 0.0f ? 4 : 1, nz = idz < 0.0f ? 5 : 2;
-    const int fx = 3 - nx, fy = 5 - ny, fz = 7 - nz;
+    s.onx = -oix - slack; s.ony = -oiy - slack; s.onz = -oiz - slack;
+    s.ofx = -oix + slack; s.ofy = -oiy + slack; s.ofz = -oiz + slack;
+    s.nx = s.idx < 0.0f ? 3 : 0;
+    s.ny = s.idy < 0.0f ? 4 : 1;
+    s.nz = s.idz < 0.0f ? 5 : 2;
+    s.best.t = tmax; s.best.u = 0.0f; s.best.v = 0.0f;
+    s.best.tri = 0xFFFFFFFFu; s.best.submesh = 0xFFFFFFFFu; s.best.prim = 0xFFFFFFFFu;
+    s.cur = 0;
+    s.sp = 0;
+}
 
-    uint2 ovf[PT_STACK_OVF];
-    int sp = 0;
-    uint32_t cur = 0;
+#define PT_PUSH(ref, key)                                                                   \
+    {                                                                                       \
+        uint2 e_ = make_uint2(ref, f2u(key));                                               \
+        if (s.sp < PT_STACK_LDS) lds_stack[s.sp * stride] = e_; else ovf[s.sp - PT_STACK_LDS] = e_; \
+        s.sp++;                                                                             \
+    }
 
-    for (;;) {
-        if (!(cur & PT_CHILD_LEAF)) {
-            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-            float4 bnx = np[nx], bny = np[ny], bnz = np[nz];
-            float4 bfx = np[fx], bfy = np[fy], bfz = np[fz];
-            uint4 ch = reinterpret_cast<const uint4*>(np)[6];
-            if (STATS) stat_nodes++;
+// pops until an entry that can still hold a closer hit; false when the stack is empty (ray finished)
+PT_DEV bool trav_pop(Trav& s, const uint2* lds_stack, int stride, const uint2* ovf)
+{
+    while (s.sp > 0) {
+        s.sp--;
+        uint2 e = (s.sp < PT_STACK_LDS) ? lds_stack[s.sp * stride] : ovf[s.sp - PT_STACK_LDS];
+        if (u2f(e.y) <= s.best.t) { s.cur = e.x; return true; }
+    }
+    return false;
+}
 
-            float tn0 = fmaxf(fmaxf(fmaf(bnx.x, idx, onx), fmaf(bny.x, idy, ony)), fmaxf(fmaf(bnz.x, idz, onz), tmin));
-            float tn1 = fmaxf(fmaxf(fmaf(bnx.y, idx, onx), fmaf(bny.y, idy, ony)), fmaxf(fmaf(bnz.y, idz, onz), tmin));
-            float tn2 = fmaxf(fmaxf(fmaf(bnx.z, idx, onx), fmaf(bny.z, idy, ony)), fmaxf(fmaf(bnz.z, idz, onz), tmin));
-            float tn3 = fmaxf(fmaxf(fmaf(bnx.w, idx, onx), fmaf(bny.w, idy, ony)), fmaxf(fmaf(bnz.w, idz, onz), tmin));
-            float tf0 = fminf(fminf(fmaf(bfx.x, idx, ofx), fmaf(bfy.x, idy, ofy)), fmaf(bfz.x, idz, ofz)) * 1.0000005f;
-            float tf1 = fminf(fminf(fmaf(bfx.y, idx, ofx), fmaf(bfy.y, idy, ofy)), fmaf(bfz.y, idz, ofz)) * 1.0000005f;
-            float tf2 = fminf(fminf(fmaf(bfx.z, idx, ofx), fmaf(bfy.z, idy, ofy)), fmaf(bfz.z, idz, ofz)) * 1.0000005f;
-            float tf3 = fminf(fminf(fmaf(bfx.w, idx, ofx), fmaf(bfy.w, idy, ofy)), fmaf(bfz.w, idz, ofz)) * 1.0000005f;
-            const float INF = __builtin_inff();
-            // a child is entered when its slab interval is non-empty and starts before the best hit
-            float k0 = (tn0 <= tf0 && tn0 <= best.t && ch.x != PT_CHILD_EMPTY) ? tn0 : INF;
-            float k1 = (tn1 <= tf1 && tn1 <= best.t && ch.y != PT_CHILD_EMPTY) ? tn1 : INF;
-            float k2 = (tn2 <= tf2 && tn2 <= best.t && ch.z != PT_CHILD_EMPTY) ? tn2 : INF;
-            float k3 = (tn3 <= tf3 && tn3 <= best.t && ch.w != PT_CHILD_EMPTY) ? tn3 : INF;
-            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+// one internal node: slab-tests the four children, follows the nearest, stacks the others
+PT_DEV bool node_step(Trav& s, const Node4* __restrict__ nodes, uint2* lds_stack, int stride, uint2* ovf)
+{
+    const float4* np = reinterpret_cast<const float4*>(nodes + s.cur);
+    const int fx = 3 - s.nx, fy = 5 - s.ny, fz = 7 - s.nz;
+    float4 bnx = np[s.nx], bny = np[s.ny], bnz = np[s.nz];
+    float4 bfx = np[fx], bfy = np[fy], bfz = np[fz];
+    uint4 ch = reinterpret_cast<const uint4*>(np)[6];
+#ifdef PT_EXTRA_LOADS
+    // experiment: extra 16-byte loads from the same node line, kept alive without being used
+    {
+        typedef float f4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int k = 0; k < PT_EXTRA_LOADS; k++) {
+            f4_ e;
+            const void* ptr = &np[k & 7];
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e) : "v"(ptr) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    const float idx = s.idx, idy = s.idy, idz = s.idz, tmin = s.tmin;
+    float tn0 = fmaxf(fmaxf(fmaf(bnx.x, idx, s.onx), fmaf(bny.x, idy, s.ony)), fmaxf(fmaf(bnz.x, idz, s.onz), tmin));
+    float tn1 = fmaxf(fmaxf(fmaf(bnx.y, idx, s.onx), fmaf(bny.y, idy, s.ony)), fmaxf(fmaf(bnz.y, idz, s.onz), tmin));
+    float tn2 = fmaxf(fmaxf(fmaf(bnx.z, idx, s.onx), fmaf(bny.z, idy, s.ony)), fmaxf(fmaf(bnz.z, idz, s.onz), tmin));
+    float tn3 = fmaxf(fmaxf(fmaf(bnx.w, idx, s.onx), fmaf(bny.w, idy, s.ony)), fmaxf(fmaf(bnz.w, idz, s.onz), tmin));
+    float tf0 = fminf(fminf(fmaf(bfx.x, idx, s.ofx), fmaf(bfy.x, idy, s.ofy)), fmaf(bfz.x, idz, s.ofz)) * 1.0000005f;
+    float tf1 = fminf(fminf(fmaf(bfx.y, idx, s.ofx), fmaf(bfy.y, idy, s.ofy)), fmaf(bfz.y, idz, s.ofz)) * 1.0000005f;
+    float tf2 = fminf(fminf(fmaf(bfx.z, idx, s.ofx), fmaf(bfy.z, idy, s.ofy)), fmaf(bfz.z, idz, s.ofz)) * 1.0000005f;
+    float tf3 = fminf(fminf(fmaf(bfx.w, idx, s.ofx), fmaf(bfy.w, idy, s.ofy)), fmaf(bfz.w, idz, s.ofz)) * 1.0000005f;
+    const float INF = __builtin_inff();
+    const float bt = s.best.t;
+    // a child is entered when its slab interval is non-empty and starts before the best hit
+    float k0 = (tn0 <= tf0 && tn0 <= bt && ch.x != PT_CHILD_EMPTY) ? tn0 : INF;
+    float k1 = (tn1 <= tf1 && tn1 <= bt && ch.y != PT_CHILD_EMPTY) ? tn1 : INF;
+    float k2 = (tn2 <= tf2 && tn2 <= bt && ch.z != PT_CHILD_EMPTY) ? tn2 : INF;
+    float k3 = (tn3 <= tf3 && tn3 <= bt && ch.w != PT_CHILD_EMPTY) ? tn3 : INF;
+    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
 #define PT_CSWAP(ka, ca, kb, cb) { if (kb < ka) { float tk = ka; ka = kb; kb = tk; uint32_t tc = ca; ca = cb; cb = tc; } }
-            PT_CSWAP(k0, c0, k1, c1)
-            PT_CSWAP(k2, c2, k3, c3)
-            PT_CSWAP(k0, c0, k2, c2)
-            PT_CSWAP(k1, c1, k3, c3)
-            PT_CSWAP(k1, c1, k2, c2)
+    PT_CSWAP(k0, c0, k1, c1)
+    PT_CSWAP(k2, c2, k3, c3)
+    PT_CSWAP(k0, c0, k2, c2)
+    PT_CSWAP(k1, c1, k3, c3)
+    PT_CSWAP(k1, c1, k2, c2)
 #undef PT_CSWAP
-            // farthest first, so the nearest is popped (or followed) first
-            if (k3 < INF) { uint2 e = make_uint2(c3, f2u(k3)); if (sp < PT_STACK_LDS) lds_stack[sp * stride] = e; else ovf[sp - PT_STACK_LDS] = e; sp++; }
-            if (k2 < INF) { uint2 e = make_uint2(c2, f2u(k2)); if (sp < PT_STACK_LDS) lds_stack[sp * stride] = e; else ovf[sp - PT_STACK_LDS] = e; sp++; }
-            if (k1 < INF) { uint2 e = make_uint2(c1, f2u(k1)); if (sp < PT_STACK_LDS) lds_stack[sp * stride] = e; else ovf[sp - PT_STACK_LDS] = e; sp++; }
-            if (k0 < INF) { cur = c0; continue; }
-        } else {
-            uint32_t first = cur & 0x0FFFFFFFu;
-            uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; i++) {
-                const float4* tp = reinterpret_cast<const float4*>(tris + first + i);
-                float4 a = tp[0], b = tp[1], c = tp[2];
-                if (STATS) stat_tris++;
-                float t, u, v;
-                if (!tri_test(rp, o, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), tmin, t, u, v)) continue;
-                if (!(t < tmax)) continue;
-                uint32_t sm = f2u(a.w), pr = f2u(b.w);
-                bool take = t < best.t ||
-                            (t == best.t && best.tri != 0xFFFFFFFFu && (sm < best.submesh || (sm == best.submesh && pr < best.prim)));
-                if (take) {
-                    best.t = t; best.u = u; best.v = v;
-                    best.tri = first + i; best.submesh = sm; best.prim = pr;
+    // farthest first, so the nearest is popped (or followed) first
+    if (k3 < INF) PT_PUSH(c3, k3)
+    if (k2 < INF) PT_PUSH(c2, k2)
+    if (k1 < INF) PT_PUSH(c1, k1)
+    if (k0 < INF) { s.cur = c0; return true; }
+    return trav_pop(s, lds_stack, stride, ovf);
+}
+
+// one leaf: tests its (up to 4) triangles, then pops
+template <bool STATS>
+PT_DEV bool leaf_step(Trav& s, const TriRec* __restrict__ tris, const uint2* lds_stack, int stride, const uint2* ovf, uint32_t& stat_tris)
+{
+    uint32_t first = s.cur & 0x0FFFFFFFu;
+    uint32_t cnt = ((s.cur >> 28) & 7u) + 1u;
+    for (uint32_t i = 0; i < cnt; i++) {
+        const float4* tp = reinterpret_cast<const float4*>(tris + first + i);
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) stat_tris++;
+        float t, u, v;
+        if (!tri_test(s.rp, s.o, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), s.tmin, t, u, v)) continue;
+        if (!(t < s.tmax)) continue;
+        uint32_t sm = f2u(a.w), pr = f2u(b.w);
+        bool take = t < s.best.t ||
+                    (t == s.best.t && s.best.tri != 0xFFFFFFFFu && (sm < s.best.submesh || (sm == s.best.submesh && pr < s.best.prim)));
+        if (take) {
+            s.best.t = t; s.best.u = u; s.best.v = v;
+            s.best.tri = first + i; s.best.submesh = sm; s.best.prim = pr;
+        }
+    }
+    return trav_pop(s, lds_stack, stride, ovf);
+}
+
+// Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue, emit(i, hit) stores
+// its result; *cursor hands out queue indices (must be 0 at launch), n = queue length.
+// lds_stack points at this lane's column: entry k is lds_stack[k * stride].
+template <bool STATS, class Fetch, class Emit>
+PT_DEV void trace_wave(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
+                       uint32_t* cursor, uint2* lds_stack, int stride, Fetch fetch, Emit emit,
+                       uint32_t& stat_nodes, uint32_t& stat_tris, uint32_t* wave_stats = nullptr)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    Trav s;
+    uint2 ovf[PT_STACK_OVF];
+    bool has = false;
+    bool exhausted = false;      // wave-uniform
+    uint32_t my = 0;
+    s.cur = 0;
+    for (;;) {
+        unsigned long long idle = __ballot(!has);
+        uint32_t nidle = (uint32_t)__popcll(idle);
+        if (!exhausted && nidle >= PT_REFILL_MIN) {
+            if (STATS && wave_stats && lane == 0) wave_stats[4]++;
+            uint32_t base = 0;
+            if (lane == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(cursor, nidle);
+            base = __shfl(base, __ffsll((long long)idle) - 1);
+            if (!has) {
+                uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    v3 o, d;
+                    float tmin, tmax;
+                    fetch(i, o, d, tmin, tmax);
+                    trav_init(s, o, d, tmin, tmax);
+                    my = i;
+                    if (num_tris == 0) emit(my, s.best);
+                    else has = true;
                 }
             }
+            if (base + nidle >= n) exhausted = true;
         }
-        // pop, dropping subtrees that start behind the current best hit
-        bool found = false;
-        while (sp > 0) {
-            sp--;
-            uint2 e = (sp < PT_STACK_LDS) ? lds_stack[sp * stride] : ovf[sp - PT_STACK_LDS];
-            if (u2f(e.y) <= best.t) { cur = e.x; found = true; break; }
+        if (__ballot(has) == 0) {
+            if (exhausted) break;
+            continue;
         }
-        if (!found) break;
+        // node phase: every lane standing on an internal node takes one step
+        bool at_node = has && !(s.cur & PT_CHILD_LEAF);
+        if (STATS && wave_stats) {
+            unsigned long long nm = __ballot(at_node);
+            if (lane == 0 && nm) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(nm); }
+        }
+        if (at_node) {
+            if (STATS) stat_nodes++;
+            if (!node_step(s, nodes, lds_stack, stride, ovf)) { emit(my, s.best); has = false; }
+        }
+        // triangle phase: once enough lanes hold a leaf, or nobody is left on a node
+        bool at_leaf = has && (s.cur & PT_CHILD_LEAF);
+        unsigned long long leafm = __ballot(at_leaf);
+        unsigned long long nodem = __ballot(has && !(s.cur & PT_CHILD_LEAF));
+        if (leafm != 0 && ((uint32_t)__popcll(leafm) >= PT_LEAF_MIN || nodem == 0)) {
+            if (STATS && wave_stats && lane == 0) { wave_stats[2]++; wave_stats[3] += (uint32_t)__popcll(leafm); }
+            if (at_leaf) {
+                if (!leaf_step<STATS>(s, tris, lds_stack, stride, ovf, stat_tris)) { emit(my, s.best); has = false; }
+            }
+        }
     }
-    return best;
 }
+
+#undef PT_PUSH
 
 } // namespace ptd

@@ -18,7 +18,9 @@ struct alignas(128) Node4 {
 
 #define PT_CHILD_EMPTY 0xFFFFFFFFu
 #define PT_CHILD_LEAF 0x80000000u
+#ifndef PT_LEAF_MAX
 #define PT_LEAF_MAX 4u
+#endif
 #define PT_SHARDS 32u     // independent sub-queues of the wavefront ray queue (multiple of the 8 XCDs)
 
 // world-space triangle, 48 bytes, in leaf order: (v0, submesh) (v1, prim) (v2, 0)

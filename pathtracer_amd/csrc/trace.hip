@@ -23,6 +23,7 @@
 #include "pt_bsdf.h"
 #include "pt_context.h"
 #include "pt_traverse.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace ptd {
@@ -127,26 +128,31 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
 
 template <bool STATS>
 __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, float tmax, const uint32_t* __restrict__ counts,
-                                                       uint32_t shard_cap, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
-                                                       float4* __restrict__ hits, unsigned long long* stats)
+                                                       uint32_t* cursors, uint32_t shard_cap, const float4* __restrict__ rayO,
+                                                       const float4* __restrict__ rayD, float4* __restrict__ hits, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
-    const uint32_t shard = blockIdx.x % PT_SHARDS, lb = blockIdx.x / PT_SHARDS, nb = gridDim.x / PT_SHARDS;
+    const uint32_t shard = blockIdx.x % PT_SHARDS;
     const uint32_t n = counts[shard];
+    const uint32_t base = shard * shard_cap;
     uint32_t sn = 0, st = 0;
-    for (uint32_t base = lb * EXT_BLOCK; base < n; base += nb * EXT_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t slot = shard * shard_cap + i;
-        if (i < n) {
-            float4 ro = rayO[slot], rd = rayD[slot];
-            HitRec h = traverse<STATS>(sc.nodes, sc.tris, sc.num_tris, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), tmin, tmax,
-                                       stack + threadIdx.x, EXT_BLOCK, sn, st);
-            hits[slot] = make_float4(h.t, h.u, h.v, u2f(h.tri));
-        }
-    }
+    uint32_t ws[5] = {0, 0, 0, 0, 0};   // wave node phases, lanes in them, wave leaf phases, lanes in them, refills
+    trace_wave<STATS>(
+        sc.nodes, sc.tris, sc.num_tris, n, &cursors[shard], stack + threadIdx.x, EXT_BLOCK,
+        [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
+            float4 ro = rayO[base + i], rd = rayD[base + i];
+            o = V3(ro.x, ro.y, ro.z);
+            d = V3(rd.x, rd.y, rd.z);
+            tn = tmin;
+            tx = tmax;
+        },
+        [&](uint32_t i, const HitRec& h) { hits[base + i] = make_float4(h.t, h.u, h.v, u2f(h.tri)); }, sn, st,
+        STATS ? ws : nullptr);
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
+        if (threadIdx.x == 0)
+            for (int k = 0; k < 5; k++) atomicAdd(&stats[3 + k], (unsigned long long)ws[k]);
     }
 }
 
@@ -452,8 +458,10 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     size_t ev = 0;
     auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
 
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(rounds + 1) * PT_SHARDS * sizeof(uint32_t), st));
-    if (counting) PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 16, st));
+    // queue sizes of every round, followed by the traversal kernel's fetch cursors of every round
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)2 * (rounds + 1) * PT_SHARDS * sizeof(uint32_t), st));
+    uint32_t* cursors = ctx->d_counts + (size_t)(rounds + 1) * PT_SHARDS;
+    if (counting) PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 64, st));
     Queues q;
     q.hits = ctx->d_hits;
     q.stA = ctx->d_stA; q.stB = ctx->d_stB; q.stC = ctx->d_stC;
@@ -480,14 +488,15 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         if (per_shard > cap_per_shard) per_shard = cap_per_shard;
         return per_shard * PT_SHARDS;
     };
-    uint32_t ext_blocks = shard_grid(npix, EXT_BLOCK, (uint32_t)ctx->num_cus * 20u);
+    static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 20u;
+    uint32_t ext_blocks = shard_grid(npix, EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu);
     uint32_t sh_blocks = shard_grid(npix, SHADE_BLOCK, max_blocks);
     for (uint32_t r = 0; r < rounds; r++) {
         int in = (int)(r & 1u), out = in ^ 1;
         if (counting)
-            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_stats);
+            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_stats);
         else
-            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
+            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
         PT_HIP(ctx, mark());
         q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
         q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
@@ -511,22 +520,25 @@ int launch_resolve(pt_ctx* ctx)
 }
 
 // ---- inspection hooks --------------------------------------------------------------------------
-__global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uint32_t n, const float4* __restrict__ rays,
+__global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uint32_t n, uint32_t* cursor, const float4* __restrict__ rays,
                                                                 uint32_t* __restrict__ out, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     uint32_t sn = 0, st = 0;
-    for (uint32_t base = blockIdx.x * EXT_BLOCK; base < n; base += gridDim.x * EXT_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        if (i < n) {
+    trace_wave<true>(
+        sc.nodes, sc.tris, sc.num_tris, n, cursor, stack + threadIdx.x, EXT_BLOCK,
+        [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rays[2 * i], rd = rays[2 * i + 1];
-            HitRec h = traverse<true>(sc.nodes, sc.tris, sc.num_tris, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, rd.w,
-                                      stack + threadIdx.x, EXT_BLOCK, sn, st);
+            o = V3(ro.x, ro.y, ro.z);
+            d = V3(rd.x, rd.y, rd.z);
+            tn = ro.w;
+            tx = rd.w;
+        },
+        [&](uint32_t i, const HitRec& h) {
             uint32_t* o = out + (size_t)i * 5;
-            if (h.tri == MISS) { o[0] = f2u(rd.w); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }
+            if (h.tri == MISS) { o[0] = f2u(h.t); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }   // h.t is still tmax
             else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = h.submesh; o[4] = h.prim; }
-        }
-    }
+        }, sn, st);
     atomicAdd(&stats[0], (unsigned long long)sn);
     atomicAdd(&stats[1], (unsigned long long)st);
 }
@@ -593,11 +605,11 @@ int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, 
     PT_HIP(ctx, d_rays.alloc(2 * (size_t)n));
     PT_HIP(ctx, d_out.alloc(5 * (size_t)n));
     PT_HIP(ctx, hipMemcpyAsync(d_rays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 16, st));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 64, st));   // two counters + the fetch cursor + wave statistics
     uint32_t blocks = (n + EXT_BLOCK - 1) / EXT_BLOCK;
     uint32_t cap = (uint32_t)ctx->num_cus * 20u;
     if (blocks > cap) blocks = cap;
-    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, d_rays.p, d_out.p, ctx->d_stats);
+    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(ctx->d_stats + 2), d_rays.p, d_out.p, ctx->d_stats);
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipMemcpyAsync(hits, d_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, st));
     unsigned long long hs[2] = {0, 0};
