@@ -137,6 +137,7 @@ void pt_destroy(pt_ctx* ctx)
     free_scene(ctx);
     free_images(ctx);
     (void)dev_free(ctx->d_counts);
+    (void)dev_free(ctx->d_spill);
     (void)dev_free(ctx->d_total_rays);
     (void)dev_free(ctx->d_stats);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);

@@ -13,8 +13,8 @@
 //         one cluster is left (k_ploc_nearest, k_ploc_flags, scan, k_ploc_merge).  Near-SAH quality.
 //      b. PT_BUILD_LBVH: binary radix tree over the sorted codes (Karras 2012, k_karras) and bottom-up
 //         boxes with an arrival counter per node (k_refit).  Fastest build, about 1.6x the traversal cost.
-//   5. k_collapse     level by level: binary tree -> 4-wide nodes of 128 bytes, subtrees of <= 4 triangles
-//                     become leaves, triangles are written out in leaf order
+//   5. k_collapse     level by level: binary tree -> 8-wide nodes of 128 bytes with 8-bit quantised child
+//                     boxes, subtrees of <= 4 triangles become leaves, triangles are written out in leaf order
 #include "pt_context.h"
 #include "pt_math.h"
 #include <hipcub/hipcub.hpp>
@@ -301,16 +301,27 @@ __device__ __forceinline__ float box_area(float4 lo, float4 hi)
 
 struct CollapseItem { uint32_t node2, slot, tstart, pad; };
 
-// one thread per frontier item: builds one Node4 and queues its internal children
+// smallest biased exponent e with extent <= 255 * 2^(e - 127)
+__device__ __forceinline__ uint32_t grid_exponent(float extent)
+{
+    float f = extent * (1.0f / 255.0f);
+    if (!(f > 1e-30f)) return 27u;                 // flat or empty axis: any tiny positive step works
+    uint32_t bits = __float_as_uint(f);
+    uint32_t e = (bits >> 23) & 255u;
+    if (bits & 0x007fffffu) e++;                   // not an exact power of two: round the step up
+    return e > 254u ? 254u : e;
+}
+
+// one thread per frontier item: builds one Node8 and queues its internal children
 __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in, CollapseItem* __restrict__ out, uint32_t* out_count,
                            uint32_t* node_counter, uint32_t* leaf_counter, int n, const uint2* __restrict__ children,
                            const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, const uint32_t* __restrict__ vals,
-                           const TriRec* __restrict__ tris_in, TriRec* __restrict__ tris_out, Node4* __restrict__ nodes, float pad)
+                           const TriRec* __restrict__ tris_in, TriRec* __restrict__ tris_out, Node8* __restrict__ nodes, float pad)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nitems) return;
     CollapseItem it = in[g];
-    uint32_t cand[4];
+    uint32_t cand[8];
     int nc;
     auto count_of = [&](uint32_t id) { return __float_as_uint(b2lo[id].w); };
     auto is_leaf2 = [&](uint32_t id) { return id >= (uint32_t)(n - 1); };
@@ -321,7 +332,8 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
         uint2 ch = children[it.node2];
         cand[0] = ch.x; cand[1] = ch.y;
         nc = 2;
-        while (nc < 4) {
+        while (nc < 8) {
+            // open the candidate with the largest box that is not going to be a leaf
             int bestk = -1;
             float besta = -1.0f;
             for (int k = 0; k < nc; k++) {
@@ -335,62 +347,96 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
             cand[nc++] = c2.y;
         }
     }
-    Node4 nd;
-    uint32_t tstart = it.tstart;
-    for (int k = 0; k < 4; k++) {
-        if (k >= nc) {
-            nd.lox[k] = nd.loy[k] = nd.loz[k] = __builtin_inff();
-            nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -__builtin_inff();
-            nd.child[k] = PT_CHILD_EMPTY;
-            continue;
-        }
-        uint32_t c = cand[k];
-        float4 lo = b2lo[c], hi = b2hi[c];
-        uint32_t cnt = __float_as_uint(lo.w);
-        nd.lox[k] = lo.x - pad; nd.loy[k] = lo.y - pad; nd.loz[k] = lo.z - pad;
-        nd.hix[k] = hi.x + pad; nd.hiy[k] = hi.y + pad; nd.hiz[k] = hi.z + pad;
-        if (cnt <= PT_LEAF_MAX) {
-            nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
-            // write the subtree's triangles in depth-first order
-            uint32_t stack[16];
-            int sp = 0;
-            uint32_t w = tstart;
-            stack[sp++] = c;
-            while (sp) {
-                uint32_t id = stack[--sp];
-                if (is_leaf2(id)) {
-                    tris_out[w++] = tris_in[vals[id - (uint32_t)(n - 1)]];
-                } else {
-                    uint2 c2 = children[id];
-                    stack[sp++] = c2.y;
-                    stack[sp++] = c2.x;
-                }
-            }
-            atomicAdd(leaf_counter, 1u);
-        } else {
-            uint32_t slot = atomicAdd(node_counter, 1u);
-            nd.child[k] = slot;
-            uint32_t o = atomicAdd(out_count, 1u);
-            out[o] = CollapseItem{c, slot, tstart, 0u};
-        }
-        tstart += cnt;
+    // the node's grid: origin = lower corner of the padded union, one power-of-two step per axis
+    float lo3[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi3[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int k = 0; k < nc; k++) {
+        float4 lo = b2lo[cand[k]], hi = b2hi[cand[k]];
+        lo3[0] = fminf(lo3[0], lo.x - pad); lo3[1] = fminf(lo3[1], lo.y - pad); lo3[2] = fminf(lo3[2], lo.z - pad);
+        hi3[0] = fmaxf(hi3[0], hi.x + pad); hi3[1] = fmaxf(hi3[1], hi.y + pad); hi3[2] = fmaxf(hi3[2], hi.z + pad);
     }
-    nd.pad[0] = nd.pad[1] = nd.pad[2] = nd.pad[3] = 0;
+    uint32_t e3[3];
+    float inv3[3];
+    for (int a = 0; a < 3; a++) {
+        e3[a] = grid_exponent(hi3[a] - lo3[a]);
+        inv3[a] = __uint_as_float((254u - e3[a]) << 23);       // 2^-(e - 127), exact
+    }
+    Node8 nd;
+    nd.origin[0] = lo3[0]; nd.origin[1] = lo3[1]; nd.origin[2] = lo3[2];
+    nd.exps = e3[0] | (e3[1] << 8) | (e3[2] << 16);
+    for (int w = 0; w < 12; w++) nd.q[w] = 0u;
+    for (int w = 0; w < 8; w++) nd.pad[w] = 0u;
+    uint32_t tstart = it.tstart;
+    for (int k = 0; k < 8; k++) {
+        uint32_t qlo[3] = {255u, 255u, 255u}, qhi[3] = {0u, 0u, 0u};
+        if (k >= nc) {
+            nd.child[k] = PT_CHILD_EMPTY;
+        } else {
+            uint32_t c = cand[k];
+            float4 lo = b2lo[c], hi = b2hi[c];
+            uint32_t cnt = __float_as_uint(lo.w);
+            float l3[3] = {lo.x - pad, lo.y - pad, lo.z - pad}, h3[3] = {hi.x + pad, hi.y + pad, hi.z + pad};
+            for (int a = 0; a < 3; a++) {
+                float ql = floorf((l3[a] - lo3[a]) * inv3[a]);
+                float qh = ceilf((h3[a] - lo3[a]) * inv3[a]);
+                qlo[a] = (uint32_t)fminf(fmaxf(ql, 0.0f), 255.0f);
+                qhi[a] = (uint32_t)fminf(fmaxf(qh, 0.0f), 255.0f);
+            }
+            if (cnt <= PT_LEAF_MAX) {
+                nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
+                // write the subtree's triangles in depth-first order
+                uint32_t stack[16];
+                int sp = 0;
+                uint32_t w = tstart;
+                stack[sp++] = c;
+                while (sp) {
+                    uint32_t id = stack[--sp];
+                    if (is_leaf2(id)) {
+                        tris_out[w++] = tris_in[vals[id - (uint32_t)(n - 1)]];
+                    } else {
+                        uint2 c2 = children[id];
+                        stack[sp++] = c2.y;
+                        stack[sp++] = c2.x;
+                    }
+                }
+                atomicAdd(leaf_counter, 1u);
+            } else {
+                uint32_t slot = atomicAdd(node_counter, 1u);
+                nd.child[k] = slot;
+                uint32_t o = atomicAdd(out_count, 1u);
+                out[o] = CollapseItem{c, slot, tstart, 0u};
+            }
+            tstart += cnt;
+        }
+        // plane p of child k is byte (k & 3) of word p * 2 + (k >> 2)
+        uint32_t sh = (uint32_t)(k & 3) * 8u;
+        int wo = k >> 2;
+        for (int a = 0; a < 3; a++) {
+            nd.q[a * 2 + wo] |= qlo[a] << sh;
+            nd.q[(3 + a) * 2 + wo] |= qhi[a] << sh;
+        }
+    }
     nodes[it.slot] = nd;
 }
 
 // surface-area-heuristic cost: sum over nodes of area(child box)/area(root) * (1 for a node, count for a leaf)
-__global__ void k_sah(uint32_t num_nodes, const Node4* __restrict__ nodes, float root_area, float* cost)
+__global__ void k_sah(uint32_t num_nodes, const Node8* __restrict__ nodes, float root_area, float* cost)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     float c = 0.0f;
     if (g < num_nodes) {
-        const Node4& nd = nodes[g];
-        for (int k = 0; k < 4; k++) {
+        const Node8& nd = nodes[g];
+        float st[3];
+        for (int a = 0; a < 3; a++) st[a] = __uint_as_float(((nd.exps >> (8 * a)) & 255u) << 23);
+        for (int k = 0; k < 8; k++) {
             uint32_t ch = nd.child[k];
             if (ch == PT_CHILD_EMPTY) continue;
-            float ex = nd.hix[k] - nd.lox[k], ey = nd.hiy[k] - nd.loy[k], ez = nd.hiz[k] - nd.loz[k];
-            float a = (ex * ey + ey * ez + ez * ex) / root_area;
+            float e[3];
+            for (int a = 0; a < 3; a++) {
+                uint32_t ql = (nd.q[a * 2 + (k >> 2)] >> ((k & 3) * 8)) & 255u;
+                uint32_t qh = (nd.q[(3 + a) * 2 + (k >> 2)] >> ((k & 3) * 8)) & 255u;
+                e[a] = (float)(qh - ql) * st[a];
+            }
+            float a = (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]) / root_area;
             if (ch & PT_CHILD_LEAF) c += a * (float)(((ch >> 28) & 7u) + 1u);
             else c += a;
         }
@@ -451,7 +497,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, fr[0].alloc(n));
     PT_HIP(ctx, fr[1].alloc(n));
     PT_HIP(ctx, cost.alloc(1));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, (size_t)n * sizeof(Node4)));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, (size_t)n * sizeof(Node8)));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_tris, (size_t)n * sizeof(TriRec)));
 
     const int B = 256;
@@ -557,8 +603,8 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
 
-    if (3u * depth + 1u > (uint32_t)(16 + 80))
-        return set_error(ctx, PT_ERR_BVH_DEPTH, "hierarchy has " + std::to_string(depth) + " levels; the traversal stack holds 96 entries (32 levels)");
+    if (7u * depth + 1u > (uint32_t)(16 + 80))
+        return set_error(ctx, PT_ERR_BVH_DEPTH, "hierarchy has " + std::to_string(depth) + " levels; the traversal stack holds 96 entries (13 levels of 8-wide nodes)");
     ctx->accel_built = true;
     return PT_OK;
 }

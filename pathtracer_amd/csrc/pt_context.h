@@ -27,7 +27,7 @@ struct pt_ctx {
     bool scene_loaded = false;
 
     // hierarchy
-    ptd::Node4* d_nodes = nullptr;
+    ptd::Node8* d_nodes = nullptr;
     ptd::TriRec* d_tris = nullptr;
     uint32_t num_nodes = 0;
     bool accel_built = false;
@@ -51,6 +51,8 @@ struct pt_ctx {
     uint32_t shard_cap = 0;         // ray-queue slots per shard
     uint32_t* d_counts = nullptr;   // PT_SHARDS per round, rounds + 1 rows of queue sizes, then as many rows of fetch cursors
     uint32_t counts_cap = 0;
+    uint2* d_spill = nullptr;       // traversal stack spill area, [wave][entry][lane]
+    uint32_t spill_waves = 0;
     unsigned long long* d_total_rays = nullptr;
     unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested, [2] fetch cursor of pt_debug_intersect
 

@@ -1,4 +1,4 @@
-// Closest-hit traversal of the 4-wide hierarchy, one ray per lane, persistent waves.
+// Closest-hit traversal of the 8-wide quantised hierarchy, one ray per lane, persistent waves.
 //
 // Replaces traceRayEXT (PathTracer/assets/shaders/RayTracing/RayGen.glsl:124), which the
 // reference leaves to the Vulkan driver and RT hardware.  Semantics: closest hit with
@@ -13,9 +13,11 @@
 // enough lanes have one (or nobody has a node left), so the triangle code runs with fuller waves.
 //
 // Stack: the first PT_STACK_LDS entries of each lane live in LDS (one column per lane,
-// conflict free), deeper entries spill to per-lane scratch.  An entry carries the
-// child's entry distance so that a popped subtree that has fallen behind the current
-// hit is dropped without fetching its node.
+// conflict free); deeper entries go to a per-wave spill area in global memory, laid out
+// [entry][lane] so that a wave's spills coalesce.  The kernel itself uses no scratch memory:
+// a private spill array would reserve tens of KB of scratch per wave and cap the number of
+// resident waves.  An entry carries the child's entry distance so that a popped subtree that
+// has fallen behind the current hit is dropped without fetching its node.
 #pragma once
 #include "pt_math.h"
 #include "pt_types.h"
@@ -103,7 +105,7 @@ struct Trav {
     float idx, idy, idz;           // 1 / direction (zero components replaced by +-1e-20)
     float onx, ony, onz;           // -(o * idir) - slack : near planes
     float ofx, ofy, ofz;           // -(o * idir) + slack : far planes
-    int nx, ny, nz;                // float4 index of the near plane arrays in a node (lo = 0..2, hi = 3..5)
+    bool negx, negy, negz;         // direction signs: pick which quantised plane of a child box is the near one
     HitRec best;
     uint32_t cur;                  // node index, or leaf reference (bit 31)
     int sp;
@@ -125,9 +127,9 @@ PT_DEV void trav_init(Trav& s, v3 o, v3 d, float tmin, float tmax)
     float slack = fmaxf(fmaxf(gabs(oix), gabs(oiy)), gabs(oiz)) * 0x1p-22f;
     s.onx = -oix - slack; s.ony = -oiy - slack; s.onz = -oiz - slack;
     s.ofx = -oix + slack; s.ofy = -oiy + slack; s.ofz = -oiz + slack;
-    s.nx = s.idx < 0.0f ? 3 : 0;
-    s.ny = s.idy < 0.0f ? 4 : 1;
-    s.nz = s.idz < 0.0f ? 5 : 2;
+    s.negx = s.idx < 0.0f;
+    s.negy = s.idy < 0.0f;
+    s.negz = s.idz < 0.0f;
     s.best.t = tmax; s.best.u = 0.0f; s.best.v = 0.0f;
     s.best.tri = 0xFFFFFFFFu; s.best.submesh = 0xFFFFFFFFu; s.best.prim = 0xFFFFFFFFu;
     s.cur = 0;
@@ -137,7 +139,7 @@ PT_DEV void trav_init(Trav& s, v3 o, v3 d, float tmin, float tmax)
 #define PT_PUSH(ref, key)                                                                   \
     {                                                                                       \
         uint2 e_ = make_uint2(ref, f2u(key));                                               \
-        if (s.sp < PT_STACK_LDS) lds_stack[s.sp * stride] = e_; else ovf[s.sp - PT_STACK_LDS] = e_; \
+        if (s.sp < PT_STACK_LDS) lds_stack[s.sp * stride] = e_; else ovf[(s.sp - PT_STACK_LDS) * 64] = e_; \
         s.sp++;                                                                             \
     }
 
@@ -146,62 +148,71 @@ PT_DEV bool trav_pop(Trav& s, const uint2* lds_stack, int stride, const uint2* o
 {
     while (s.sp > 0) {
         s.sp--;
-        uint2 e = (s.sp < PT_STACK_LDS) ? lds_stack[s.sp * stride] : ovf[s.sp - PT_STACK_LDS];
+        uint2 e = (s.sp < PT_STACK_LDS) ? lds_stack[s.sp * stride] : ovf[(s.sp - PT_STACK_LDS) * 64];
         if (u2f(e.y) <= s.best.t) { s.cur = e.x; return true; }
     }
     return false;
 }
 
-// one internal node: slab-tests the four children, follows the nearest, stacks the others
-PT_DEV bool node_step(Trav& s, const Node4* __restrict__ nodes, uint2* lds_stack, int stride, uint2* ovf)
+PT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); }
+
+// child reference number `slot` (0..7) out of the eight held in registers
+PT_DEV uint32_t pick_child(uint4 c03, uint4 c47, uint32_t slot)
 {
-    const float4* np = reinterpret_cast<const float4*>(nodes + s.cur);
-    const int fx = 3 - s.nx, fy = 5 - s.ny, fz = 7 - s.nz;
-    float4 bnx = np[s.nx], bny = np[s.ny], bnz = np[s.nz];
-    float4 bfx = np[fx], bfy = np[fy], bfz = np[fz];
-    uint4 ch = reinterpret_cast<const uint4*>(np)[6];
-#ifdef PT_EXTRA_LOADS
-    // experiment: extra 16-byte loads from the same node line, kept alive without being used
-    {
-        typedef float f4_ __attribute__((ext_vector_type(4)));
+    uint32_t a = (slot & 4u) ? c47.x : c03.x, b = (slot & 4u) ? c47.y : c03.y;
+    uint32_t c = (slot & 4u) ? c47.z : c03.z, d = (slot & 4u) ? c47.w : c03.w;
+    uint32_t e = (slot & 2u) ? c : a, f = (slot & 2u) ? d : b;
+    return (slot & 1u) ? f : e;
+}
+
+#define PT_KEY_MISS 0x7f800000u
+
+// one internal node: decodes the eight quantised child boxes, slab-tests them, follows the nearest
+// hit child and stacks the others, farthest first.  A sort key is the entry distance with the
+// child's slot number in its three lowest mantissa bits, so the eight candidates are ordered with a
+// 19-comparator network of integer min/max.
+PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack, int stride, uint2* ovf)
+{
+    const uint4* np = reinterpret_cast<const uint4*>(nodes + s.cur);
+    uint4 hdr = np[0], c03 = np[1], c47 = np[2], qa = np[3], qb = np[4], qc = np[5];
+    // plane = origin + q * step  =>  t = q * (step * idir) + (origin * idir - o * idir -+ slack)
+    float ox = u2f(hdr.x), oy = u2f(hdr.y), oz = u2f(hdr.z);
+    float ax = u2f((hdr.w & 255u) << 23) * s.idx;
+    float ay = u2f(((hdr.w >> 8) & 255u) << 23) * s.idy;
+    float az = u2f(((hdr.w >> 16) & 255u) << 23) * s.idz;
+    float bnx = fmaf(ox, s.idx, s.onx), bny = fmaf(oy, s.idy, s.ony), bnz = fmaf(oz, s.idz, s.onz);
+    float bfx = fmaf(ox, s.idx, s.ofx), bfy = fmaf(oy, s.idy, s.ofy), bfz = fmaf(oz, s.idz, s.ofz);
+    // q words: qa = lo.x[0..7] lo.y[0..7], qb = lo.z[0..7] hi.x[0..7], qc = hi.y[0..7] hi.z[0..7]
+    uint32_t nxw[2] = {s.negx ? qb.z : qa.x, s.negx ? qb.w : qa.y}, fxw[2] = {s.negx ? qa.x : qb.z, s.negx ? qa.y : qb.w};
+    uint32_t nyw[2] = {s.negy ? qc.x : qa.z, s.negy ? qc.y : qa.w}, fyw[2] = {s.negy ? qa.z : qc.x, s.negy ? qa.w : qc.y};
+    uint32_t nzw[2] = {s.negz ? qc.z : qb.x, s.negz ? qc.w : qb.y}, fzw[2] = {s.negz ? qb.x : qc.z, s.negz ? qb.y : qc.w};
+    const float bt = s.best.t, tmin = s.tmin;
+    uint32_t key[8];
 #pragma unroll
-        for (int k = 0; k < PT_EXTRA_LOADS; k++) {
-            f4_ e;
-            const void* ptr = &np[k & 7];
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e) : "v"(ptr) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k = 0; k < 8; k++) {
+        const int w = k >> 2, b = k & 3;
+        float tn = fmaxf(fmaxf(fmaf(ubyte_f(nxw[w], b), ax, bnx), fmaf(ubyte_f(nyw[w], b), ay, bny)),
+                         fmaxf(fmaf(ubyte_f(nzw[w], b), az, bnz), tmin));
+        float tf = fminf(fminf(fmaf(ubyte_f(fxw[w], b), ax, bfx), fmaf(ubyte_f(fyw[w], b), ay, bfy)),
+                         fmaf(ubyte_f(fzw[w], b), az, bfz)) * 1.0000005f;
+        // entered when the slab interval is non-empty and starts before the best hit (empty children decode to tn > tf)
+        bool hit = tn <= fminf(tf, bt);
+        key[k] = hit ? ((f2u(tn) & 0x7ffffff8u) | (uint32_t)k) : (PT_KEY_MISS | (uint32_t)k);
     }
-#endif
-    const float idx = s.idx, idy = s.idy, idz = s.idz, tmin = s.tmin;
-    float tn0 = fmaxf(fmaxf(fmaf(bnx.x, idx, s.onx), fmaf(bny.x, idy, s.ony)), fmaxf(fmaf(bnz.x, idz, s.onz), tmin));
-    float tn1 = fmaxf(fmaxf(fmaf(bnx.y, idx, s.onx), fmaf(bny.y, idy, s.ony)), fmaxf(fmaf(bnz.y, idz, s.onz), tmin));
-    float tn2 = fmaxf(fmaxf(fmaf(bnx.z, idx, s.onx), fmaf(bny.z, idy, s.ony)), fmaxf(fmaf(bnz.z, idz, s.onz), tmin));
-    float tn3 = fmaxf(fmaxf(fmaf(bnx.w, idx, s.onx), fmaf(bny.w, idy, s.ony)), fmaxf(fmaf(bnz.w, idz, s.onz), tmin));
-    float tf0 = fminf(fminf(fmaf(bfx.x, idx, s.ofx), fmaf(bfy.x, idy, s.ofy)), fmaf(bfz.x, idz, s.ofz)) * 1.0000005f;
-    float tf1 = fminf(fminf(fmaf(bfx.y, idx, s.ofx), fmaf(bfy.y, idy, s.ofy)), fmaf(bfz.y, idz, s.ofz)) * 1.0000005f;
-    float tf2 = fminf(fminf(fmaf(bfx.z, idx, s.ofx), fmaf(bfy.z, idy, s.ofy)), fmaf(bfz.z, idz, s.ofz)) * 1.0000005f;
-    float tf3 = fminf(fminf(fmaf(bfx.w, idx, s.ofx), fmaf(bfy.w, idy, s.ofy)), fmaf(bfz.w, idz, s.ofz)) * 1.0000005f;
-    const float INF = __builtin_inff();
-    const float bt = s.best.t;
-    // a child is entered when its slab interval is non-empty and starts before the best hit
-    float k0 = (tn0 <= tf0 && tn0 <= bt && ch.x != PT_CHILD_EMPTY) ? tn0 : INF;
-    float k1 = (tn1 <= tf1 && tn1 <= bt && ch.y != PT_CHILD_EMPTY) ? tn1 : INF;
-    float k2 = (tn2 <= tf2 && tn2 <= bt && ch.z != PT_CHILD_EMPTY) ? tn2 : INF;
-    float k3 = (tn3 <= tf3 && tn3 <= bt && ch.w != PT_CHILD_EMPTY) ? tn3 : INF;
-    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-#define PT_CSWAP(ka, ca, kb, cb) { if (kb < ka) { float tk = ka; ka = kb; kb = tk; uint32_t tc = ca; ca = cb; cb = tc; } }
-    PT_CSWAP(k0, c0, k1, c1)
-    PT_CSWAP(k2, c2, k3, c3)
-    PT_CSWAP(k0, c0, k2, c2)
-    PT_CSWAP(k1, c1, k3, c3)
-    PT_CSWAP(k1, c1, k2, c2)
-#undef PT_CSWAP
+#define PT_CE(i, j) { uint32_t lo_ = min(key[i], key[j]); key[j] = max(key[i], key[j]); key[i] = lo_; }
+    PT_CE(0, 1) PT_CE(2, 3) PT_CE(4, 5) PT_CE(6, 7)
+    PT_CE(0, 2) PT_CE(1, 3) PT_CE(4, 6) PT_CE(5, 7)
+    PT_CE(1, 2) PT_CE(5, 6)
+    PT_CE(0, 4) PT_CE(1, 5) PT_CE(2, 6) PT_CE(3, 7)
+    PT_CE(2, 4) PT_CE(3, 5)
+    PT_CE(1, 2) PT_CE(3, 4) PT_CE(5, 6)
+#undef PT_CE
     // farthest first, so the nearest is popped (or followed) first
-    if (k3 < INF) PT_PUSH(c3, k3)
-    if (k2 < INF) PT_PUSH(c2, k2)
-    if (k1 < INF) PT_PUSH(c1, k1)
-    if (k0 < INF) { s.cur = c0; return true; }
+#pragma unroll
+    for (int j = 7; j >= 1; j--) {
+        if (key[j] < PT_KEY_MISS) PT_PUSH(pick_child(c03, c47, key[j] & 7u), u2f(key[j] & 0x7ffffff8u))
+    }
+    if (key[0] < PT_KEY_MISS) { s.cur = pick_child(c03, c47, key[0] & 7u); return true; }
     return trav_pop(s, lds_stack, stride, ovf);
 }
 
@@ -231,15 +242,15 @@ PT_DEV bool leaf_step(Trav& s, const TriRec* __restrict__ tris, const uint2* lds
 
 // Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue, emit(i, hit) stores
 // its result; *cursor hands out queue indices (must be 0 at launch), n = queue length.
-// lds_stack points at this lane's column: entry k is lds_stack[k * stride].
+// lds_stack points at this lane's column: entry k is lds_stack[k * stride]; ovf points at this lane's
+// column of the wave's global spill area: entry k is ovf[k * 64].
 template <bool STATS, class Fetch, class Emit>
-PT_DEV void trace_wave(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
-                       uint32_t* cursor, uint2* lds_stack, int stride, Fetch fetch, Emit emit,
+PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
+                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, Fetch fetch, Emit emit,
                        uint32_t& stat_nodes, uint32_t& stat_tris, uint32_t* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     Trav s;
-    uint2 ovf[PT_STACK_OVF];
     bool has = false;
     bool exhausted = false;      // wave-uniform
     uint32_t my = 0;

@@ -4,16 +4,23 @@
 
 namespace ptd {
 
-// 4-wide hierarchy node, 128 bytes = one L2 cache line.  Child boxes are stored
-// structure-of-arrays so four slab tests read eight 16-byte vectors.
-// child[k]: 0xFFFFFFFF = empty; bit 31 set = leaf with triangles
-// [first, first+count) where first = bits 0..27 and count-1 = bits 28..30;
-// otherwise the index of another node.
-struct alignas(128) Node4 {
-    float lox[4], loy[4], loz[4];
-    float hix[4], hiy[4], hiz[4];
-    uint32_t child[4];
-    uint32_t pad[4];
+// 8-wide hierarchy node, 128 bytes = one L2 cache line.  Child boxes are quantised to 8 bits per
+// plane on a per-node grid: plane = origin + q * 2^(exp - 127), rounded outwards, so a decoded box
+// always contains the exact one.  The whole hierarchy of a Sponza-class scene is then ~2 MB and
+// stays in every XCD's 4 MB L2.
+//   words 0..2   origin x, y, z (float)
+//   word  3      exponent bytes: x | y << 8 | z << 16 (biased like a float exponent)
+//   words 4..11  child[8]: 0xFFFFFFFF = empty; bit 31 set = leaf with triangles [first, first+count)
+//                where first = bits 0..27 and count-1 = bits 28..30; otherwise a node index
+//   words 12..23 quantised planes, 8 bytes (one per child) each: lo.x lo.y lo.z hi.x hi.y hi.z
+//                (an empty child has lo = 255 and hi = 0 on every axis and can never be entered)
+//   words 24..31 unused
+struct alignas(128) Node8 {
+    float origin[3];
+    uint32_t exps;
+    uint32_t child[8];
+    uint32_t q[12];
+    uint32_t pad[8];
 };
 
 #define PT_CHILD_EMPTY 0xFFFFFFFFu
@@ -51,7 +58,7 @@ struct SceneView {
     const float* env;           // 6 * n * n * 4
     uint32_t env_n;
     uint32_t num_tris;
-    const Node4* nodes;
+    const Node8* nodes;
     const TriRec* tris;
 };
 

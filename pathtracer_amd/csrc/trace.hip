@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
 template <bool STATS>
 __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, float tmax, const uint32_t* __restrict__ counts,
                                                        uint32_t* cursors, uint32_t shard_cap, const float4* __restrict__ rayO,
-                                                       const float4* __restrict__ rayD, float4* __restrict__ hits, unsigned long long* stats)
+                                                       const float4* __restrict__ rayD, float4* __restrict__ hits, uint2* spill,
+                                                       unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     const uint32_t shard = blockIdx.x % PT_SHARDS;
@@ -139,6 +140,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, 
     uint32_t ws[5] = {0, 0, 0, 0, 0};   // wave node phases, lanes in them, wave leaf phases, lanes in them, refills
     trace_wave<STATS>(
         sc.nodes, sc.tris, sc.num_tris, n, &cursors[shard], stack + threadIdx.x, EXT_BLOCK,
+        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rayO[base + i], rd = rayD[base + i];
             o = V3(ro.x, ro.y, ro.z);
@@ -412,6 +414,17 @@ __global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __
     reinterpret_cast<float4*>(image)[g] = out;
 }
 
+// global spill area of the traversal stacks: one [PT_STACK_OVF][64] block of entries per wave
+static int ensure_spill(pt_ctx* ctx, uint32_t waves)
+{
+    if (waves <= ctx->spill_waves) return PT_OK;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_spill) { (void)hipFree(ctx->d_spill); ctx->d_spill = nullptr; ctx->spill_waves = 0; }
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_spill, (size_t)waves * PT_STACK_OVF * 64 * sizeof(uint2)));
+    ctx->spill_waves = waves;
+    return PT_OK;
+}
+
 SceneView scene_view(const pt_ctx* ctx)
 {
     SceneView sv;
@@ -490,13 +503,17 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     };
     static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 20u;
     uint32_t ext_blocks = shard_grid(npix, EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu);
+    {
+        int rc = ensure_spill(ctx, ext_blocks);
+        if (rc) return rc;
+    }
     uint32_t sh_blocks = shard_grid(npix, SHADE_BLOCK, max_blocks);
     for (uint32_t r = 0; r < rounds; r++) {
         int in = (int)(r & 1u), out = in ^ 1;
         if (counting)
-            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_stats);
+            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_spill, ctx->d_stats);
         else
-            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, nullptr);
+            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_spill, nullptr);
         PT_HIP(ctx, mark());
         q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
         q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
@@ -521,12 +538,13 @@ int launch_resolve(pt_ctx* ctx)
 
 // ---- inspection hooks --------------------------------------------------------------------------
 __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uint32_t n, uint32_t* cursor, const float4* __restrict__ rays,
-                                                                uint32_t* __restrict__ out, unsigned long long* stats)
+                                                                uint32_t* __restrict__ out, uint2* spill, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     uint32_t sn = 0, st = 0;
     trace_wave<true>(
         sc.nodes, sc.tris, sc.num_tris, n, cursor, stack + threadIdx.x, EXT_BLOCK,
+        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rays[2 * i], rd = rays[2 * i + 1];
             o = V3(ro.x, ro.y, ro.z);
@@ -609,7 +627,11 @@ int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, 
     uint32_t blocks = (n + EXT_BLOCK - 1) / EXT_BLOCK;
     uint32_t cap = (uint32_t)ctx->num_cus * 20u;
     if (blocks > cap) blocks = cap;
-    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(ctx->d_stats + 2), d_rays.p, d_out.p, ctx->d_stats);
+    {
+        int rc = ensure_spill(ctx, blocks);
+        if (rc) return rc;
+    }
+    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(ctx->d_stats + 2), d_rays.p, d_out.p, ctx->d_spill, ctx->d_stats);
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipMemcpyAsync(hits, d_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, st));
     unsigned long long hs[2] = {0, 0};

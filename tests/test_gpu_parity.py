@@ -173,7 +173,7 @@ def test_tie_rule_and_watertight_edges(backend):
     sc = SceneData(v, idx, [(0, 4, 6, 0), (0, 0, 0, 0)], [6, 6], ident, [make_material()])
     backend.scene_upload(sc)
     st = backend.build_accel()
-    assert st.num_triangles == 4 and st.num_nodes == 1
+    assert st.num_triangles == 4 and st.num_nodes == 1 and st.num_leaves == 1
     o = oracle_lib.Oracle(sc)
     rng = np.random.default_rng(1)
     rays = random_rays(rng, 2000, [-1.2, -1.2, 0], [1.2, 1.2, 1])
@@ -187,42 +187,70 @@ def test_tie_rule_and_watertight_edges(backend):
     assert (hg[~inside, 3] == M32).all()
 
 
+def decode_child_boxes(node_words):
+    """(lo, hi) arrays of shape (8, 3) and the 8 child references of one 128-byte node."""
+    origin = node_words[0:3].view(np.float32).astype(np.float64)
+    exps = int(node_words[3])
+    step = np.array([2.0 ** (((exps >> (8 * a)) & 255) - 127) for a in range(3)])
+    q = node_words[12:24]
+    lo = np.zeros((8, 3))
+    hi = np.zeros((8, 3))
+    for k in range(8):
+        for a in range(3):
+            ql = (int(q[a * 2 + (k >> 2)]) >> ((k & 3) * 8)) & 255
+            qh = (int(q[(3 + a) * 2 + (k >> 2)]) >> ((k & 3) * 8)) & 255
+            lo[k, a] = origin[a] + ql * step[a]
+            hi[k, a] = origin[a] + qh * step[a]
+    return lo, hi, node_words[4:12]
+
+
 def test_hierarchy_is_well_formed(backend, cornell):
     backend.scene_upload(cornell)
     st = backend.build_accel()
     nodes, tris = backend.debug_read_bvh()
-    nf = nodes.view(np.float32)
+    assert nodes.shape == (st.num_nodes, 32)
     seen = np.zeros(st.num_triangles, bool)
     visited = np.zeros(st.num_nodes, bool)
-    tv = tris.view(np.float32).reshape(-1, 3, 4)[:, :, :3]
-    stack = [0]
+    tv = tris.view(np.float32).reshape(-1, 3, 4)[:, :, :3].astype(np.float64)
+    leaves = 0
+    stack = [(0, [])]
     while stack:
-        i = stack.pop()
+        i, boxes = stack.pop()
         assert not visited[i]
         visited[i] = True
-        for k in range(4):
-            ch = int(nodes[i, 24 + k])
+        lo, hi, child = decode_child_boxes(nodes[i])
+        for k in range(8):
+            ch = int(child[k])
             if ch == M32:
+                assert (lo[k] > hi[k]).all()          # an empty child can never be entered
                 continue
-            lo = np.array([nf[i, k], nf[i, 4 + k], nf[i, 8 + k]])
-            hi = np.array([nf[i, 12 + k], nf[i, 16 + k], nf[i, 20 + k]])
+            mine = boxes + [(lo[k], hi[k])]
             if ch & 0x80000000:
                 first, cnt = ch & 0x0FFFFFFF, ((ch >> 28) & 7) + 1
                 assert cnt <= 4 and not seen[first:first + cnt].any()
                 seen[first:first + cnt] = True
+                leaves += 1
                 p = tv[first:first + cnt].reshape(-1, 3)
-                assert (p >= lo).all() and (p <= hi).all()
+                for (blo, bhi) in mine:               # every ancestor's decoded box contains the triangles
+                    assert (p >= blo).all() and (p <= bhi).all()
             else:
-                cf = nf[ch]
-                used = nodes[ch, 24:28] != M32
-                assert (cf[0:4][used] >= lo[0]).all() and (cf[12:16][used] <= hi[0]).all()
-                assert (cf[4:8][used] >= lo[1]).all() and (cf[16:20][used] <= hi[1]).all()
-                assert (cf[8:12][used] >= lo[2]).all() and (cf[20:24][used] <= hi[2]).all()
-                stack.append(ch)
-    assert seen.all() and visited.all()
+                stack.append((ch, mine))
+    assert seen.all() and visited.all() and leaves == st.num_leaves
     # every (submesh, prim) appears exactly once
     ids = tris[:, 3].astype(np.uint64) << np.uint64(32) | tris[:, 7].astype(np.uint64)
     assert len(np.unique(ids)) == st.num_triangles
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_both_builders_give_the_same_hits(backend, cornell, flags):
+    # 0 = agglomerative clustering, 1 = Morton radix tree only: the hierarchy must not change any result
+    backend.scene_upload(cornell)
+    backend.build_accel(flags)
+    rng = np.random.default_rng(31 + flags)
+    rays = random_rays(rng, 50000, [-0.35, -0.05, -0.6], [0.3, 0.6, 0.8])
+    o = oracle_lib.Oracle(cornell)
+    hg, _ = backend.debug_intersect(rays)
+    assert np.array_equal(hg, o.intersect(rays, use_bvh=True))
 
 
 # ---- frames --------------------------------------------------------------------------------------------------
