@@ -59,39 +59,74 @@ static int finish_timing(pt_ctx* ctx)
     if (!ctx->timing_pending) return PT_OK;
     ctx->timing_pending = false;
     pt_trace_timing t{};
-    uint32_t R = ctx->timing_rounds;
-    std::vector<hipEvent_t>& ev = ctx->events;
-    float ms = 0.0f;
-    PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
-    t.raygen_ms = ms;
+    const uint32_t R = ctx->timing_rounds, C = ctx->timing_chains, spc = PT_SHARDS / C;
     // device-side queue sizes tell which rounds had work
-    std::vector<uint32_t> shard_counts((size_t)(R + 1) * PT_SHARDS);
-    PT_HIP(ctx, hipMemcpy(shard_counts.data(), ctx->d_counts, shard_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<uint64_t> counts(R + 1, 0);
-    for (uint32_t r = 0; r <= R; r++)
-        for (uint32_t k = 0; k < PT_SHARDS; k++) counts[r] += shard_counts[(size_t)r * PT_SHARDS + k];
-    for (uint32_t r = 0; r < R; r++) {
-        float e = 0.0f, s = 0.0f;
-        PT_HIP(ctx, hipEventElapsedTime(&e, ev[1 + 2 * r], ev[2 + 2 * r]));
-        PT_HIP(ctx, hipEventElapsedTime(&s, ev[2 + 2 * r], ev[3 + 2 * r]));
-        if (counts[r] > 0) {
-            t.extend_ms += e; t.shade_ms += s;
-            t.extend_launches++; t.shade_launches++;
+    const size_t chain_words = (size_t)2 * (R + 1) * spc;
+    std::vector<uint32_t> words(chain_words * C);
+    PT_HIP(ctx, hipMemcpy(words.data(), ctx->d_counts, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    float first = 0.0f, last = 0.0f;
+    for (uint32_t c = 0; c < C; c++) {
+        std::vector<hipEvent_t>& ev = ctx->events[c];
+        float ms = 0.0f;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
+        t.raygen_ms += ms;
+        for (uint32_t r = 0; r < R; r++) {
+            uint64_t queued = 0;
+            for (uint32_t k = 0; k < spc; k++) queued += words[c * chain_words + (size_t)r * spc + k];
+            float e = 0.0f, sh = 0.0f;
+            PT_HIP(ctx, hipEventElapsedTime(&e, ev[1 + 2 * r], ev[2 + 2 * r]));
+            PT_HIP(ctx, hipEventElapsedTime(&sh, ev[2 + 2 * r], ev[3 + 2 * r]));
+            if (queued > 0) {
+                t.extend_ms += e; t.shade_ms += sh;
+                t.extend_launches++; t.shade_launches++;
+            }
+            t.rays += queued;
         }
-        t.rays += counts[r];
+        // frame time: first chain start to last chain end, both measured from chain 0's first event
+        float a = 0.0f, b = 0.0f;
+        if (c > 0) PT_HIP(ctx, hipEventElapsedTime(&a, ctx->events[0][0], ev[0]));
+        PT_HIP(ctx, hipEventElapsedTime(&b, ctx->events[0][0], ev[2 + 2 * R]));
+        if (c == 0 || a < first) first = a;
+        if (c == 0 || b > last) last = b;
     }
-    PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[2 + 2 * R]));
-    t.total_ms = ms;
+    t.total_ms = last - first;
     if (ctx->profiling == 2) {
-        unsigned long long hs[8] = {0};
-        PT_HIP(ctx, hipMemcpy(hs, ctx->d_stats, 64, hipMemcpyDeviceToHost));
+        unsigned long long hs[16] = {0};
+        PT_HIP(ctx, hipMemcpy(hs, ctx->d_stats, 128, hipMemcpyDeviceToHost));
         t.nodes_visited = hs[0];
         t.tris_tested = hs[1];
         if (getenv("PT_WAVE_STATS"))
-            fprintf(stderr, "wave stats: node phases %llu (lanes %llu, %.1f/64), leaf phases %llu (lanes %llu, %.1f/64), refills %llu\n",
-                    hs[3], hs[4], hs[3] ? (double)hs[4] / hs[3] : 0.0, hs[5], hs[6], hs[5] ? (double)hs[6] / hs[5] : 0.0, hs[7]);
+            fprintf(stderr, "wave stats: node phases %llu (lanes %llu, %.1f/64), leaf phases %llu (lanes %llu, %.1f/64), refills %llu, wave ms: draining %.1f of resident %.1f, longest ray %llu steps\n",
+                    hs[3], hs[4], hs[3] ? (double)hs[4] / hs[3] : 0.0, hs[5], hs[6], hs[5] ? (double)hs[6] / hs[5] : 0.0, hs[7], hs[8] * 1e-5, hs[9] * 1e-5, hs[10]);
+        const char* path = getenv("PT_WAVE_TRACE");
+        if (path && ctx->d_wave_trace) {
+            size_t len = (size_t)ctx->wave_trace_rounds * ctx->wave_trace_waves * 4;
+            std::vector<unsigned long long> buf(len + 2);
+            buf[0] = ctx->wave_trace_rounds; buf[1] = ctx->wave_trace_waves;
+            PT_HIP(ctx, hipMemcpy(buf.data() + 2, ctx->d_wave_trace, len * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(path, "wb")) { fwrite(buf.data(), sizeof(unsigned long long), buf.size(), f); fclose(f); }
+        }
     }
     ctx->timing = t;
+    return PT_OK;
+}
+
+int sync_streams(pt_ctx* ctx)
+{
+    for (uint32_t c = ctx->chains; c-- > 0;)
+        if (ctx->chain_stream[c]) PT_HIP(ctx, hipStreamSynchronize(ctx->chain_stream[c]));
+    ctx->join_pending = false;
+    return PT_OK;
+}
+
+int join_chains(pt_ctx* ctx)
+{
+    if (!ctx->join_pending) return PT_OK;
+    for (uint32_t c = 1; c < ctx->chains; c++) {
+        PT_HIP(ctx, hipEventRecord(ctx->chain_done[c], ctx->chain_stream[c]));
+        PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain_done[c], 0));
+    }
+    ctx->join_pending = false;
     return PT_OK;
 }
 
@@ -120,11 +155,21 @@ int pt_create(int device_ordinal, pt_ctx** out)
     ctx->num_cus = prop.multiProcessorCount;
     pt_default_params(&ctx->params);
     hipError_t es = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    ctx->chain_stream[0] = ctx->stream;
+    uint32_t chains = PT_MAX_CHAINS;
+    if (const char* e = getenv("PT_CHAINS")) chains = (uint32_t)atoi(e);
+    if (chains < 1 || chains > PT_MAX_CHAINS || PT_SHARDS % chains) chains = PT_MAX_CHAINS;
+    ctx->chains = chains;
+    for (uint32_t c = 1; c < chains && es == hipSuccess; c++) {
+        es = hipStreamCreateWithFlags(&ctx->chain_stream[c], hipStreamNonBlocking);
+        if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming);
+    }
+    if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
     hipError_t e1 = hipMalloc((void**)&ctx->d_total_rays, 8);
-    hipError_t e2 = hipMalloc((void**)&ctx->d_stats, 64);
+    hipError_t e2 = hipMalloc((void**)&ctx->d_stats, 128);
     if (es != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) { pt_destroy(ctx); return set_error(nullptr, PT_ERR_HIP, "context allocation failed"); }
     (void)hipMemset(ctx->d_total_rays, 0, 8);
-    (void)hipMemset(ctx->d_stats, 0, 64);
+    (void)hipMemset(ctx->d_stats, 0, 128);
     *out = ctx;
     return PT_OK;
 }
@@ -133,14 +178,21 @@ void pt_destroy(pt_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_streams(ctx);
     free_scene(ctx);
     free_images(ctx);
     (void)dev_free(ctx->d_counts);
     (void)dev_free(ctx->d_spill);
+    (void)dev_free(ctx->d_wave_trace);
     (void)dev_free(ctx->d_total_rays);
     (void)dev_free(ctx->d_stats);
-    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    for (auto& v : ctx->events)
+        for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    for (uint32_t c = 1; c < PT_MAX_CHAINS; c++) {
+        if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
+        if (ctx->chain_stream[c]) (void)hipStreamDestroy(ctx->chain_stream[c]);
+    }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -192,7 +244,7 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* s)
         if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 || s->textures[t].flags != 0)
             return set_error(ctx, PT_ERR_INVALID, "texture " + std::to_string(t) + " is empty or has unknown flags");
 
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     free_scene(ctx);
     int rc;
     if ((rc = upload(ctx, ctx->d_vertices, s->vertices, (size_t)s->num_vertices * 12))) return rc;
@@ -227,7 +279,7 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* s)
         ctx->env_n = 1;
         if ((rc = upload(ctx, ctx->d_env, (const float*)white, 24))) return rc;
     }
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host arrays may go away after return
+    PT_SYNC(ctx);   // the host arrays may go away after return
     ctx->num_vertices = s->num_vertices; ctx->num_indices = s->num_indices; ctx->num_submeshes = s->num_submeshes;
     ctx->num_materials = s->num_materials; ctx->num_textures = s->num_textures;
     ctx->num_tris = tri_off[s->num_submeshes];
@@ -258,8 +310,9 @@ int pt_update_materials(pt_ctx* ctx, const float* materials, uint32_t num_materi
                 return set_error(ctx, PT_ERR_INVALID, "material names a texture that was not supplied");
         }
     PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_SYNC(ctx);
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_materials, materials, (size_t)num_materials * 88, hipMemcpyHostToDevice, ctx->stream));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     return PT_OK;
 }
 
@@ -269,7 +322,7 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
     if (width == 0 || height == 0) return set_error(ctx, PT_ERR_INVALID, "pt_resize: empty image");
     if ((uint64_t)width * height > (1ull << 28)) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_resize: more than 2^28 pixels");
     PT_HIP(ctx, hipSetDevice(ctx->device));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     free_images(ctx);
     size_t n = (size_t)width * height;
     size_t tiles = (size_t)((width + 7) / 8) * ((height + 7) / 8);
@@ -289,6 +342,7 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
     PT_HIP(ctx, hipMemsetAsync(ctx->d_image_own, 0, n * 16, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_accum_own, 0, n * 16, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, n * 8, ctx->stream));
+    ctx->main_dirty = true;
     ctx->d_image = ctx->d_image_own;
     ctx->d_accum = ctx->d_accum_own;
     ctx->width = width;
@@ -300,7 +354,7 @@ int pt_bind_images(pt_ctx* ctx, void* device_image, void* device_accum)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "pt_bind_images: call pt_resize first");
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     ctx->d_image = device_image ? (float*)device_image : ctx->d_image_own;
     ctx->d_accum = device_accum ? (float*)device_accum : ctx->d_accum_own;
     return PT_OK;
@@ -329,7 +383,7 @@ int pt_set_profiling(pt_ctx* ctx, int mode)
     if (!ctx) return PT_ERR_INVALID;
     if (mode < 0 || mode > 2) return set_error(ctx, PT_ERR_INVALID, "pt_set_profiling: mode must be 0, 1 or 2");
     if (ctx->timing_pending) {
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PT_SYNC(ctx);
         int rc = finish_timing(ctx);
         if (rc) return rc;
     }
@@ -347,13 +401,13 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
     PT_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t rounds = ctx->params.spp_per_frame * ctx->params.max_bounces;
     if (rounds + 1 > ctx->counts_cap) {
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PT_SYNC(ctx);
         (void)dev_free(ctx->d_counts);
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (size_t)2 * (rounds + 1) * PT_SHARDS * sizeof(uint32_t)));
         ctx->counts_cap = rounds + 1;
     }
     if (ctx->timing_pending) {   // a profiled frame is still in flight: collect it before its events are reused
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PT_SYNC(ctx);
         int rc = finish_timing(ctx);
         if (rc) return rc;
     }
@@ -363,7 +417,7 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
 int pt_sync(pt_ctx* ctx)
 {
     if (!ctx) return PT_ERR_INVALID;
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     return finish_timing(ctx);
 }
 
@@ -371,8 +425,9 @@ static int read_back(pt_ctx* ctx, void* host, const void* dev, size_t bytes)
 {
     if (!host) return PT_ERR_INVALID;
     if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "no image: call pt_resize first");
+    PT_SYNC(ctx);    // every chain, not only the main stream the copy runs on
     PT_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     return finish_timing(ctx);
 }
 
@@ -384,8 +439,9 @@ int pt_write_accum(pt_ctx* ctx, const float* rgba)
 {
     if (!ctx || !rgba) return PT_ERR_INVALID;
     if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "no image: call pt_resize first");
+    PT_SYNC(ctx);
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_accum, rgba, (size_t)ctx->width * ctx->height * 16, hipMemcpyHostToDevice, ctx->stream));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     return PT_OK;
 }
 
@@ -401,8 +457,9 @@ int pt_ray_count(pt_ctx* ctx, uint64_t* rays)
 {
     if (!ctx || !rays) return PT_ERR_INVALID;
     unsigned long long v = 0;
+    PT_SYNC(ctx);
     PT_HIP(ctx, hipMemcpyAsync(&v, ctx->d_total_rays, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     *rays = v;
     return finish_timing(ctx);
 }
@@ -411,7 +468,7 @@ int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out)
 {
     if (!ctx || !out) return PT_ERR_INVALID;
     if (ctx->timing_pending) {
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PT_SYNC(ctx);
         int rc = finish_timing(ctx);
         if (rc) return rc;
     }
@@ -419,7 +476,15 @@ int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out)
     return PT_OK;
 }
 
-void* pt_stream(pt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+void* pt_stream(pt_ctx* ctx)
+{
+    if (!ctx) return nullptr;
+    // the caller is about to order its own work after ours on this stream: bring the other chains in,
+    // and order the next frame after whatever the caller enqueues
+    if (join_chains(ctx) != PT_OK) return nullptr;
+    ctx->main_dirty = true;
+    return (void*)ctx->stream;
+}
 void* pt_device_image(pt_ctx* ctx) { return ctx ? (void*)ctx->d_image : nullptr; }
 void* pt_device_accum(pt_ctx* ctx) { return ctx ? (void*)ctx->d_accum : nullptr; }
 
@@ -461,7 +526,7 @@ int pt_debug_read_bvh(pt_ctx* ctx, uint32_t* nodes, uint32_t* tris)
     if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_debug_read_bvh: hierarchy missing");
     if (nodes && ctx->num_nodes) PT_HIP(ctx, hipMemcpyAsync(nodes, ctx->d_nodes, (size_t)ctx->num_nodes * 128, hipMemcpyDeviceToHost, ctx->stream));
     if (tris && ctx->num_tris) PT_HIP(ctx, hipMemcpyAsync(tris, ctx->d_tris, (size_t)ctx->num_tris * 48, hipMemcpyDeviceToHost, ctx->stream));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     return PT_OK;
 }
 

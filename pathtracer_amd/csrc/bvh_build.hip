@@ -454,6 +454,7 @@ struct DevBuf {
 
 int build_accel(pt_ctx* ctx, uint32_t flags)
 {
+    PT_SYNC(ctx);
     hipStream_t st = ctx->stream;
     uint32_t n = ctx->num_tris;
     if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }

@@ -1,4 +1,4 @@
-// Host-side state of one rendering context (one GPU, one stream).
+// Host-side state of one rendering context (one GPU; one main stream plus the streams of the other chains).
 #pragma once
 #include "../../include/pathtracer_amd.h"
 #include "pt_types.h"
@@ -9,8 +9,19 @@
 struct pt_ctx {
     int device = 0;
     int num_cus = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // main stream = stream of chain 0
     std::string error;
+
+    // A frame is traced as `chains` independent pipelines, each owning PT_SHARDS / chains ray-queue shards (and the
+    // pixel tiles that map to them) and running raygen -> (extend -> shade)* on its own stream.  The long tail of
+    // one chain's traversal launch then overlaps the other chains' work.  Chains are not joined at the end of
+    // pt_trace: consecutive frames flow through each chain back to back; anything that reads results joins first.
+    uint32_t chains = 1;
+    hipStream_t chain_stream[PT_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t chain_done[PT_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    bool main_dirty = true;      // the main stream got work the other chains have not yet been ordered after
+    bool join_pending = false;   // the other chains got work the main stream has not yet been ordered after
 
     // scene tables (device) and their host-side sizes
     float* d_vertices = nullptr;
@@ -49,10 +60,13 @@ struct pt_ctx {
     float4* d_stB = nullptr;
     float4* d_stC = nullptr;
     uint32_t shard_cap = 0;         // ray-queue slots per shard
-    uint32_t* d_counts = nullptr;   // PT_SHARDS per round, rounds + 1 rows of queue sizes, then as many rows of fetch cursors
+    uint32_t* d_counts = nullptr;   // per chain: rounds + 1 rows of queue sizes (one per shard of the chain), then as many rows of fetch cursors
     uint32_t counts_cap = 0;
-    uint2* d_spill = nullptr;       // traversal stack spill area, [wave][entry][lane]
+    uint2* d_spill = nullptr;       // traversal stack spill area, [chain][wave][entry][lane]
     uint32_t spill_waves = 0;
+    unsigned long long* d_wave_trace = nullptr;   // PT_WAVE_TRACE=<file>: per-wave timeline of the extend launches
+    size_t wave_trace_len = 0;
+    uint32_t wave_trace_rounds = 0, wave_trace_waves = 0;
     unsigned long long* d_total_rays = nullptr;
     unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested, [2] fetch cursor of pt_debug_intersect
 
@@ -62,7 +76,8 @@ struct pt_ctx {
 
     // per-kernel timing of the last frame
     int profiling = 0;           // 0 off, 1 events, 2 events + traversal counters
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events[PT_MAX_CHAINS];
+    uint32_t timing_chains = 0;
     pt_trace_timing timing{};
     uint32_t timing_rounds = 0;
     bool timing_pending = false;
@@ -74,12 +89,20 @@ int set_error(pt_ctx* ctx, int code, const std::string& msg);
 int build_accel(pt_ctx* ctx, uint32_t flags);
 int launch_trace(pt_ctx* ctx, uint32_t frame_index);
 int launch_resolve(pt_ctx* ctx);
+int sync_streams(pt_ctx* ctx);     // host waits for every chain
+int join_chains(pt_ctx* ctx);      // main stream waits for the other chains (no host wait)
 int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
 int debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n);
 int debug_disney(pt_ctx* ctx, bool sample, uint32_t n, const float* surf, const float* V, const float* N,
                  const float* Lin, uint32_t* seeds, float* f, float* Lout, float* pdf);
 SceneView scene_view(const pt_ctx* ctx);
 } // namespace ptd
+
+#define PT_SYNC(ctx)                                                                              \
+    do {                                                                                          \
+        int rc_ = ptd::sync_streams(ctx);                                                         \
+        if (rc_) return rc_;                                                                      \
+    } while (0)
 
 #define PT_HIP(ctx, call)                                                                         \
     do {                                                                                          \

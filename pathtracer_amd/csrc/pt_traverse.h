@@ -12,9 +12,9 @@
 // fetch).  Node steps and leaf steps are separate phases: lanes that reached a leaf wait until
 // enough lanes have one (or nobody has a node left), so the triangle code runs with fuller waves.
 //
-// Stack: the first PT_STACK_LDS entries of each lane live in LDS (one column per lane,
-// conflict free); deeper entries go to a per-wave spill area in global memory, laid out
-// [entry][lane] so that a wave's spills coalesce.  The kernel itself uses no scratch memory:
+// Stack: the top PT_STACK_LDS entries of each lane live in an LDS ring (one column per lane,
+// conflict free); deeper entries move in blocks to a per-wave spill area in global memory, laid
+// out [entry][lane] so that a wave's spills coalesce.  The kernel itself uses no scratch memory:
 // a private spill array would reserve tens of KB of scratch per wave and cap the number of
 // resident waves.  An entry carries the child's entry distance so that a popped subtree that
 // has fallen behind the current hit is dropped without fetching its node.
@@ -24,10 +24,10 @@
 
 namespace ptd {
 
-#define PT_STACK_LDS 16
-#ifndef PT_STACK_OVF
-#define PT_STACK_OVF 80    // host refuses hierarchies whose depth could need more than LDS+OVF entries
-#endif
+#define PT_STACK_LDS 16     // ring in LDS, power of two
+#define PT_STACK_BLK 8      // entries moved per spill / restore
+#define PT_STACK_MAX 96     // host refuses hierarchies whose depth could need more entries than this
+#define PT_STACK_OVF PT_STACK_MAX   // entries per lane in the global spill area
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 20   // free lanes that trigger a refill
 #endif
@@ -39,6 +39,15 @@ struct HitRec {
     float t, u, v;
     uint32_t tri;          // index into the TriRec array, 0xFFFFFFFF = miss
     uint32_t submesh, prim;
+};
+
+// what one wave did during a launch (statistics builds only); times are wall_clock64() ticks (10 ns)
+struct WaveStats {
+    uint32_t node_phases = 0, node_lanes = 0;      // node phases run, lanes active in them
+    uint32_t leaf_phases = 0, leaf_lanes = 0;
+    uint32_t refills = 0;
+    uint32_t longest_ray = 0;                      // loop iterations the longest-lived ray of this wave stayed in flight
+    unsigned long long t_start = 0, t_exhausted = 0, t_end = 0;   // t_exhausted: the queue ran dry, only own rays left
 };
 
 struct RayPre {
@@ -108,7 +117,7 @@ struct Trav {
     bool negx, negy, negz;         // direction signs: pick which quantised plane of a child box is the near one
     HitRec best;
     uint32_t cur;                  // node index, or leaf reference (bit 31)
-    int sp;
+    int sp, base;                  // stack depth; entries below base are in the spill area
 };
 
 PT_DEV void trav_init(Trav& s, v3 o, v3 d, float tmin, float tmax)
@@ -134,21 +143,41 @@ PT_DEV void trav_init(Trav& s, v3 o, v3 d, float tmin, float tmax)
     s.best.tri = 0xFFFFFFFFu; s.best.submesh = 0xFFFFFFFFu; s.best.prim = 0xFFFFFFFFu;
     s.cur = 0;
     s.sp = 0;
+    s.base = 0;
+}
+
+// The LDS part of the stack is a ring of PT_STACK_LDS entries holding the top of the logical
+// stack: entries [s.base, s.sp) live in ring slot (k % PT_STACK_LDS), entries [0, s.base) in the
+// global spill area.  Blocks of PT_STACK_BLK entries move between the two, so pushes and pops
+// themselves are plain LDS accesses.
+
+// makes room for `room` pushes (room <= PT_STACK_LDS - PT_STACK_BLK)
+PT_DEV void stack_reserve(Trav& s, const uint2* lds_stack, int stride, uint2* ovf, int room)
+{
+    if (s.sp - s.base + room > PT_STACK_LDS) {
+#pragma unroll
+        for (int i = 0; i < PT_STACK_BLK; i++) ovf[(s.base + i) * 64] = lds_stack[((s.base + i) & (PT_STACK_LDS - 1)) * stride];
+        s.base += PT_STACK_BLK;
+    }
 }
 
 #define PT_PUSH(ref, key)                                                                   \
     {                                                                                       \
-        uint2 e_ = make_uint2(ref, f2u(key));                                               \
-        if (s.sp < PT_STACK_LDS) lds_stack[s.sp * stride] = e_; else ovf[(s.sp - PT_STACK_LDS) * 64] = e_; \
+        lds_stack[(s.sp & (PT_STACK_LDS - 1)) * stride] = make_uint2(ref, f2u(key));        \
         s.sp++;                                                                             \
     }
 
 // pops until an entry that can still hold a closer hit; false when the stack is empty (ray finished)
-PT_DEV bool trav_pop(Trav& s, const uint2* lds_stack, int stride, const uint2* ovf)
+PT_DEV bool trav_pop(Trav& s, uint2* lds_stack, int stride, const uint2* ovf)
 {
     while (s.sp > 0) {
+        if (s.sp == s.base) {
+            s.base -= PT_STACK_BLK;
+#pragma unroll
+            for (int i = 0; i < PT_STACK_BLK; i++) lds_stack[((s.base + i) & (PT_STACK_LDS - 1)) * stride] = ovf[(s.base + i) * 64];
+        }
         s.sp--;
-        uint2 e = (s.sp < PT_STACK_LDS) ? lds_stack[s.sp * stride] : ovf[(s.sp - PT_STACK_LDS) * 64];
+        uint2 e = lds_stack[(s.sp & (PT_STACK_LDS - 1)) * stride];
         if (u2f(e.y) <= s.best.t) { s.cur = e.x; return true; }
     }
     return false;
@@ -208,6 +237,7 @@ PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack
     PT_CE(1, 2) PT_CE(3, 4) PT_CE(5, 6)
 #undef PT_CE
     // farthest first, so the nearest is popped (or followed) first
+    stack_reserve(s, lds_stack, stride, ovf, 7);
 #pragma unroll
     for (int j = 7; j >= 1; j--) {
         if (key[j] < PT_KEY_MISS) PT_PUSH(pick_child(c03, c47, key[j] & 7u), u2f(key[j] & 0x7ffffff8u))
@@ -218,7 +248,7 @@ PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack
 
 // one leaf: tests its (up to 4) triangles, then pops
 template <bool STATS>
-PT_DEV bool leaf_step(Trav& s, const TriRec* __restrict__ tris, const uint2* lds_stack, int stride, const uint2* ovf, uint32_t& stat_tris)
+PT_DEV bool leaf_step(Trav& s, const TriRec* __restrict__ tris, uint2* lds_stack, int stride, const uint2* ovf, uint32_t& stat_tris)
 {
     uint32_t first = s.cur & 0x0FFFFFFFu;
     uint32_t cnt = ((s.cur >> 28) & 7u) + 1u;
@@ -247,7 +277,7 @@ PT_DEV bool leaf_step(Trav& s, const TriRec* __restrict__ tris, const uint2* lds
 template <bool STATS, class Fetch, class Emit>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
                        uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, Fetch fetch, Emit emit,
-                       uint32_t& stat_nodes, uint32_t& stat_tris, uint32_t* wave_stats = nullptr)
+                       uint32_t& stat_nodes, uint32_t& stat_tris, WaveStats* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     Trav s;
@@ -255,11 +285,14 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
     bool exhausted = false;      // wave-uniform
     uint32_t my = 0;
     s.cur = 0;
+    unsigned long long t_start = 0, t_exh = 0;
+    uint32_t ray_steps = 0, ray_steps_max = 0;
+    if (STATS && wave_stats) t_start = wall_clock64();
     for (;;) {
         unsigned long long idle = __ballot(!has);
         uint32_t nidle = (uint32_t)__popcll(idle);
         if (!exhausted && nidle >= PT_REFILL_MIN) {
-            if (STATS && wave_stats && lane == 0) wave_stats[4]++;
+            if (STATS && wave_stats && lane == 0) wave_stats->refills++;
             uint32_t base = 0;
             if (lane == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(cursor, nidle);
             base = __shfl(base, __ffsll((long long)idle) - 1);
@@ -271,11 +304,15 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
                     fetch(i, o, d, tmin, tmax);
                     trav_init(s, o, d, tmin, tmax);
                     my = i;
+                    ray_steps = 0;
                     if (num_tris == 0) emit(my, s.best);
                     else has = true;
                 }
             }
-            if (base + nidle >= n) exhausted = true;
+            if (base + nidle >= n) {
+                exhausted = true;
+                if (STATS && wave_stats) t_exh = wall_clock64();
+            }
         }
         if (__ballot(has) == 0) {
             if (exhausted) break;
@@ -285,8 +322,9 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         bool at_node = has && !(s.cur & PT_CHILD_LEAF);
         if (STATS && wave_stats) {
             unsigned long long nm = __ballot(at_node);
-            if (lane == 0 && nm) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(nm); }
+            if (lane == 0 && nm) { wave_stats->node_phases++; wave_stats->node_lanes += (uint32_t)__popcll(nm); }
         }
+        if (STATS && has) { ray_steps++; ray_steps_max = max(ray_steps_max, ray_steps); }
         if (at_node) {
             if (STATS) stat_nodes++;
             if (!node_step(s, nodes, lds_stack, stride, ovf)) { emit(my, s.best); has = false; }
@@ -296,11 +334,19 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         unsigned long long leafm = __ballot(at_leaf);
         unsigned long long nodem = __ballot(has && !(s.cur & PT_CHILD_LEAF));
         if (leafm != 0 && ((uint32_t)__popcll(leafm) >= PT_LEAF_MIN || nodem == 0)) {
-            if (STATS && wave_stats && lane == 0) { wave_stats[2]++; wave_stats[3] += (uint32_t)__popcll(leafm); }
+            if (STATS && wave_stats && lane == 0) { wave_stats->leaf_phases++; wave_stats->leaf_lanes += (uint32_t)__popcll(leafm); }
             if (at_leaf) {
                 if (!leaf_step<STATS>(s, tris, lds_stack, stride, ovf, stat_tris)) { emit(my, s.best); has = false; }
             }
         }
+    }
+    if (STATS && wave_stats) {
+        unsigned long long t_end = wall_clock64();
+        wave_stats->t_start = t_start;
+        wave_stats->t_exhausted = t_exh ? t_exh : t_end;
+        wave_stats->t_end = t_end;
+        for (int o = 32; o > 0; o >>= 1) ray_steps_max = max(ray_steps_max, (uint32_t)__shfl_xor((int)ray_steps_max, o));
+        wave_stats->longest_ray = ray_steps_max;
     }
 }
 

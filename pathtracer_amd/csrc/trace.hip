@@ -37,7 +37,8 @@ struct Queues {
     float4* rayO_out; float4* rayD_out;
     float4* hits;
     float4* stA; float4* stB; float4* stC;
-    uint32_t* counts;       // counts[r * PT_SHARDS + s] = rays queued in shard s for round r
+    uint32_t* counts;       // of this chain: counts[r * nshards + ls] = rays queued in its shard ls for round r
+    uint32_t shard0, nshards;   // the chain owns shards [shard0, shard0 + nshards)
     uint32_t shard_cap;     // slots per shard; shard s owns slots [s * shard_cap, (s + 1) * shard_cap)
     uint2* primary;
     float* image; float* accum;
@@ -102,12 +103,19 @@ PT_DEV uint32_t wave_append(bool alive, uint32_t* counter)
 
 __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
 {
+    // tile t belongs to shard t % PT_SHARDS; this chain's j-th tile is the one below
     uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
-    uint32_t nslots = tiles * 64u;
+    uint32_t full = tiles / PT_SHARDS, rest = tiles % PT_SHARDS;
+    uint32_t extra = rest > q.shard0 ? (rest - q.shard0 < q.nshards ? rest - q.shard0 : q.nshards) : 0u;
+    uint32_t nslots = (full * q.nshards + extra) * 64u;
     for (uint32_t base = blockIdx.x * blockDim.x; base < nslots; base += gridDim.x * blockDim.x) {
-        uint32_t slot = base + threadIdx.x;
+        uint32_t cs = base + threadIdx.x;
+        uint32_t j = cs >> 6;
+        uint32_t ls = j % q.nshards;                   // one tile per wave: wave-uniform
+        uint32_t tile = (j / q.nshards) * PT_SHARDS + q.shard0 + ls;
+        uint32_t slot = tile * 64u + (cs & 63u);
         uint32_t x = 0, y = 0;
-        bool valid = slot < nslots && slot_to_pixel(slot, P.width, P.height, x, y);
+        bool valid = cs < nslots && slot_to_pixel(slot, P.width, P.height, x, y);
         v3 o = V3(0.0f), d = V3(0.0f);
         uint32_t pixel = 0;
         if (valid) {
@@ -117,8 +125,7 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
             q.stA[pixel] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
             q.stB[pixel] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
         }
-        uint32_t shard = (slot >> 6) % PT_SHARDS;      // one tile per wave: wave-uniform
-        uint32_t out = shard * q.shard_cap + wave_append(valid, &q.counts[shard]);
+        uint32_t out = (q.shard0 + ls) * q.shard_cap + wave_append(valid, &q.counts[ls]);
         if (valid) {
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
             q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -128,18 +135,18 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
 
 template <bool STATS>
 __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, float tmax, const uint32_t* __restrict__ counts,
-                                                       uint32_t* cursors, uint32_t shard_cap, const float4* __restrict__ rayO,
+                                                       uint32_t* cursors, uint32_t shard0, uint32_t nshards, uint32_t shard_cap, const float4* __restrict__ rayO,
                                                        const float4* __restrict__ rayD, float4* __restrict__ hits, uint2* spill,
-                                                       unsigned long long* stats)
+                                                       unsigned long long* stats, unsigned long long* wave_trace)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
-    const uint32_t shard = blockIdx.x % PT_SHARDS;
-    const uint32_t n = counts[shard];
-    const uint32_t base = shard * shard_cap;
+    const uint32_t ls = blockIdx.x % nshards;
+    const uint32_t n = counts[ls];
+    const uint32_t base = (shard0 + ls) * shard_cap;
     uint32_t sn = 0, st = 0;
-    uint32_t ws[5] = {0, 0, 0, 0, 0};   // wave node phases, lanes in them, wave leaf phases, lanes in them, refills
+    WaveStats ws;
     trace_wave<STATS>(
-        sc.nodes, sc.tris, sc.num_tris, n, &cursors[shard], stack + threadIdx.x, EXT_BLOCK,
+        sc.nodes, sc.tris, sc.num_tris, n, &cursors[ls], stack + threadIdx.x, EXT_BLOCK,
         spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rayO[base + i], rd = rayD[base + i];
@@ -149,12 +156,25 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, 
             tx = tmax;
         },
         [&](uint32_t i, const HitRec& h) { hits[base + i] = make_float4(h.t, h.u, h.v, u2f(h.tri)); }, sn, st,
-        STATS ? ws : nullptr);
+        STATS ? &ws : nullptr);
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
-        if (threadIdx.x == 0)
-            for (int k = 0; k < 5; k++) atomicAdd(&stats[3 + k], (unsigned long long)ws[k]);
+        if (threadIdx.x == 0) {
+            atomicAdd(&stats[3], (unsigned long long)ws.node_phases);
+            atomicAdd(&stats[4], (unsigned long long)ws.node_lanes);
+            atomicAdd(&stats[5], (unsigned long long)ws.leaf_phases);
+            atomicAdd(&stats[6], (unsigned long long)ws.leaf_lanes);
+            atomicAdd(&stats[7], (unsigned long long)ws.refills);
+            atomicAdd(&stats[8], ws.t_end - ws.t_exhausted);
+            atomicAdd(&stats[9], ws.t_end - ws.t_start);
+            atomicMax(&stats[10], (unsigned long long)ws.longest_ray);
+            if (wave_trace) {
+                unsigned long long* w = wave_trace + (size_t)blockIdx.x * 4;
+                w[0] = ws.t_start; w[1] = ws.t_exhausted; w[2] = ws.t_end;
+                w[3] = (unsigned long long)ws.longest_ray | ((unsigned long long)ws.node_phases << 32);
+            }
+        }
     }
 }
 
@@ -306,8 +326,9 @@ PT_DEV void write_pixel(const TraceParams& P, const Queues& q, uint32_t pixel, v
 
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
 {
-    const uint32_t shard = blockIdx.x % PT_SHARDS, lb = blockIdx.x / PT_SHARDS, nb = gridDim.x / PT_SHARDS;
-    const uint32_t n = q.counts[round * PT_SHARDS + shard];
+    const uint32_t ls = blockIdx.x % q.nshards, lb = blockIdx.x / q.nshards, nb = gridDim.x / q.nshards;
+    const uint32_t shard = q.shard0 + ls;
+    const uint32_t n = q.counts[round * q.nshards + ls];
     for (uint32_t base = lb * SHADE_BLOCK; base < n; base += nb * SHADE_BLOCK) {
         uint32_t slot = shard * q.shard_cap + base + threadIdx.x;
         bool valid = base + threadIdx.x < n;
@@ -387,7 +408,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
                 q.stB[pixel] = make_float4(rad.x, rad.y, rad.z, u2f(bounce | (sample << 16)));
             }
         }
-        uint32_t out = shard * q.shard_cap + wave_append(alive, &q.counts[(round + 1) * PT_SHARDS + shard]);
+        uint32_t out = shard * q.shard_cap + wave_append(alive, &q.counts[(round + 1) * q.nshards + ls]);
         if (alive) {
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
             q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -395,13 +416,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
     }
 }
 
-__global__ void k_finish(const uint32_t* counts, uint32_t rounds, unsigned long long* total)
+__global__ void k_finish(const uint32_t* counts, uint32_t entries, unsigned long long* total)
 {
-    // one wave: rays traced this frame = sum of all queue sizes
+    // one wave per chain: rays traced this frame = sum of all its queue sizes
     unsigned long long s = 0;
-    for (uint32_t r = threadIdx.x; r < rounds * PT_SHARDS; r += 64) s += counts[r];
+    for (uint32_t r = threadIdx.x; r < entries; r += 64) s += counts[r];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (threadIdx.x == 0) *total += s;
+    if (threadIdx.x == 0) atomicAdd(total, s);
 }
 
 __global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __restrict__ image)
@@ -418,7 +439,7 @@ __global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __
 static int ensure_spill(pt_ctx* ctx, uint32_t waves)
 {
     if (waves <= ctx->spill_waves) return PT_OK;
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_SYNC(ctx);
     if (ctx->d_spill) { (void)hipFree(ctx->d_spill); ctx->d_spill = nullptr; ctx->spill_waves = 0; }
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_spill, (size_t)waves * PT_STACK_OVF * 64 * sizeof(uint2)));
     ctx->spill_waves = waves;
@@ -445,7 +466,6 @@ SceneView scene_view(const pt_ctx* ctx)
 
 int launch_trace(pt_ctx* ctx, uint32_t frame)
 {
-    hipStream_t st = ctx->stream;
     const pt_params& pp = ctx->params;
     uint32_t npix = ctx->width * ctx->height;
     uint32_t rounds = pp.spp_per_frame * pp.max_bounces;
@@ -460,76 +480,118 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
 
     const bool prof = ctx->profiling != 0;
     const bool counting = ctx->profiling == 2;
+    const bool wave_trace = counting && getenv("PT_WAVE_TRACE");
+    const uint32_t chains = ctx->chains;
+    const uint32_t spc = PT_SHARDS / chains;                  // shards per chain
     size_t need_events = 2 + 2 * (size_t)rounds + 1;
     if (prof) {
-        while (ctx->events.size() < need_events) {
-            hipEvent_t e;
-            PT_HIP(ctx, hipEventCreate(&e));
-            ctx->events.push_back(e);
-        }
+        PT_SYNC(ctx);        // a profiled frame does not overlap its neighbours
+        for (uint32_t c = 0; c < chains; c++)
+            while (ctx->events[c].size() < need_events) {
+                hipEvent_t e;
+                PT_HIP(ctx, hipEventCreate(&e));
+                ctx->events[c].push_back(e);
+            }
     }
-    size_t ev = 0;
-    auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
 
-    // queue sizes of every round, followed by the traversal kernel's fetch cursors of every round
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)2 * (rounds + 1) * PT_SHARDS * sizeof(uint32_t), st));
-    uint32_t* cursors = ctx->d_counts + (size_t)(rounds + 1) * PT_SHARDS;
-    if (counting) PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 64, st));
-    Queues q;
-    q.hits = ctx->d_hits;
-    q.stA = ctx->d_stA; q.stB = ctx->d_stB; q.stC = ctx->d_stC;
-    q.counts = ctx->d_counts;
-    q.shard_cap = ctx->shard_cap;
-    q.primary = ctx->d_primary;
-    q.image = ctx->d_image; q.accum = ctx->d_accum;
-
-    uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
-    PT_HIP(ctx, mark());
-    {
-        q.rayO_in = q.rayO_out = ctx->d_rayO[0];
-        q.rayD_in = q.rayD_out = ctx->d_rayD[0];
-        uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
-        uint32_t blocks = (tiles * 64u + 255u) / 256u;
-        if (blocks > max_blocks) blocks = max_blocks;
-        k_raygen<<<blocks, 256, 0, st>>>(P, q);
-    }
-    PT_HIP(ctx, mark());
-    // grids are multiples of PT_SHARDS: workgroup b serves shard b % PT_SHARDS
-    auto shard_grid = [](uint32_t items, uint32_t block, uint32_t cap) {
-        uint32_t per_shard = (items / PT_SHARDS + block) / block;
-        uint32_t cap_per_shard = cap / PT_SHARDS ? cap / PT_SHARDS : 1u;
+    // workgroup b of a chain's grid serves the chain's shard b % spc
+    auto chain_grid = [&](uint32_t block, uint32_t cap_total) {
+        uint32_t per_shard = (npix / PT_SHARDS + block) / block;
+        uint32_t cap_per_shard = cap_total / PT_SHARDS ? cap_total / PT_SHARDS : 1u;
         if (per_shard > cap_per_shard) per_shard = cap_per_shard;
-        return per_shard * PT_SHARDS;
+        return per_shard * spc;
     };
     static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 20u;
-    uint32_t ext_blocks = shard_grid(npix, EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu);
+    uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
+    uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu);
+    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, max_blocks);
     {
-        int rc = ensure_spill(ctx, ext_blocks);
+        int rc = ensure_spill(ctx, ext_blocks * chains);
         if (rc) return rc;
     }
-    uint32_t sh_blocks = shard_grid(npix, SHADE_BLOCK, max_blocks);
-    for (uint32_t r = 0; r < rounds; r++) {
-        int in = (int)(r & 1u), out = in ^ 1;
-        if (counting)
-            k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_spill, ctx->d_stats);
-        else
-            k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, ctx->d_counts + r * PT_SHARDS, cursors + r * PT_SHARDS, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, ctx->d_spill, nullptr);
+    if (counting) {
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 128, ctx->stream));
+        ctx->main_dirty = true;
+    }
+    if (wave_trace) {
+        // per-wave timeline of every extend launch, dumped by the timing read-out: [chain][round][wave]{start, exhausted, end, info}
+        size_t need = (size_t)chains * rounds * ext_blocks * 4;
+        if (need > ctx->wave_trace_len) {
+            if (ctx->d_wave_trace) (void)hipFree(ctx->d_wave_trace);
+            ctx->d_wave_trace = nullptr;
+            PT_HIP(ctx, hipMalloc((void**)&ctx->d_wave_trace, need * sizeof(unsigned long long)));
+            ctx->wave_trace_len = need;
+        }
+        ctx->wave_trace_rounds = rounds * chains;
+        ctx->wave_trace_waves = ext_blocks;
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_trace, 0, need * sizeof(unsigned long long), ctx->stream));
+        ctx->main_dirty = true;
+    }
+    if (ctx->main_dirty && chains > 1) {
+        PT_HIP(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+        for (uint32_t c = 1; c < chains; c++) PT_HIP(ctx, hipStreamWaitEvent(ctx->chain_stream[c], ctx->fork_event, 0));
+    }
+    ctx->main_dirty = false;
+
+    const size_t chain_words = (size_t)2 * (rounds + 1) * spc;     // queue sizes, then fetch cursors
+    uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
+    for (uint32_t c = 0; c < chains; c++) {
+        hipStream_t st = ctx->chain_stream[c];
+        size_t ev = 0;
+        auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(ctx->events[c][ev++], st) : hipSuccess; };
+        uint32_t* counts = ctx->d_counts + c * chain_words;
+        uint32_t* cursors = counts + (size_t)(rounds + 1) * spc;
+        PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
+        Queues q;
+        q.hits = ctx->d_hits;
+        q.stA = ctx->d_stA; q.stB = ctx->d_stB; q.stC = ctx->d_stC;
+        q.counts = counts;
+        q.shard0 = c * spc; q.nshards = spc;
+        q.shard_cap = ctx->shard_cap;
+        q.primary = ctx->d_primary;
+        q.image = ctx->d_image; q.accum = ctx->d_accum;
+        uint2* spill = ctx->d_spill + (size_t)c * ext_blocks * (PT_STACK_OVF * 64);
+
         PT_HIP(ctx, mark());
-        q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
-        q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
-        k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
+        {
+            q.rayO_in = q.rayO_out = ctx->d_rayO[0];
+            q.rayD_in = q.rayD_out = ctx->d_rayD[0];
+            uint32_t blocks = ((tiles / chains + spc) * 64u + 255u) / 256u;
+            if (blocks > max_blocks) blocks = max_blocks;
+            k_raygen<<<blocks, 256, 0, st>>>(P, q);
+        }
+        PT_HIP(ctx, mark());
+        for (uint32_t r = 0; r < rounds; r++) {
+            int in = (int)(r & 1u), out = in ^ 1;
+            if (counting)
+                k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(
+                    sv, P.tmin, P.tmax, counts + r * spc, cursors + r * spc, q.shard0, spc, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in],
+                    ctx->d_hits, spill, ctx->d_stats, wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr);
+            else
+                k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, counts + r * spc, cursors + r * spc, q.shard0, spc, ctx->shard_cap,
+                                                                  ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, spill, nullptr, nullptr);
+            PT_HIP(ctx, mark());
+            q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
+            q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
+            k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
+            PT_HIP(ctx, mark());
+        }
+        k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, ctx->d_total_rays);
         PT_HIP(ctx, mark());
     }
-    k_finish<<<1, 64, 0, st>>>(ctx->d_counts, rounds, ctx->d_total_rays);
-    PT_HIP(ctx, mark());
     PT_HIP(ctx, hipGetLastError());
+    ctx->join_pending = chains > 1;
     ctx->timing_rounds = rounds;
+    ctx->timing_chains = chains;
     ctx->timing_pending = prof;
     return PT_OK;
 }
 
 int launch_resolve(pt_ctx* ctx)
 {
+    int rc = join_chains(ctx);
+    if (rc) return rc;
+    ctx->main_dirty = true;
     uint32_t n = ctx->width * ctx->height;
     k_resolve<<<(n + 255) / 256, 256, 0, ctx->stream>>>(n, ctx->d_accum, ctx->d_image);
     PT_HIP(ctx, hipGetLastError());
@@ -617,13 +679,14 @@ struct Tmp {
 
 int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters)
 {
+    PT_SYNC(ctx);
     hipStream_t st = ctx->stream;
     Tmp<float4> d_rays;
     Tmp<uint32_t> d_out;
     PT_HIP(ctx, d_rays.alloc(2 * (size_t)n));
     PT_HIP(ctx, d_out.alloc(5 * (size_t)n));
     PT_HIP(ctx, hipMemcpyAsync(d_rays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 64, st));   // two counters + the fetch cursor + wave statistics
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 128, st));   // two counters + the fetch cursor + wave statistics
     uint32_t blocks = (n + EXT_BLOCK - 1) / EXT_BLOCK;
     uint32_t cap = (uint32_t)ctx->num_cus * 20u;
     if (blocks > cap) blocks = cap;
