@@ -12,8 +12,11 @@ max-over-ranks wall time, inputs resident in HBM.
 Also reported on the same JSON line:
   roofline     dominant kernel (k_extend): algorithmic bytes (ray 32 B read + hit 16 B write per ray,
                128 B per hierarchy node visited, 48 B per triangle tested; counted by the kernel's own
-               counting variant) / its average launch time from HIP events on the launch stream,
-               against the 8 TB/s HBM peak
+               counting variant) against the 8 TB/s HBM peak.  A frame runs as `chains` pipelines side by
+               side, so `concurrency` launches of the kernel share the chip at a time: avg_launch_ms is the
+               average duration of one launch (HIP events on the stream it runs on; what rocprofv3 reports),
+               achieved = alg_bytes_per_launch / avg_launch_ms * concurrency = all launches' bytes / the
+               time during which at least one of them was running
   cpu_baseline the CPU oracle (a port of the reference shaders, not the reference itself) on the
                host cores, rank 0, bounded sample of the same workload
 """
@@ -22,6 +25,10 @@ import json
 import os
 import sys
 import time
+
+# one hardware queue per chain (8 chains); HIP reads this when its runtime starts (its default is 4)
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -145,13 +152,16 @@ def main():
         # ---- roofline of the dominant kernel: timed pass (HIP events per launch), then a counting pass ----
         b.set_profiling(1)
         ext_ms = ext_launches = prof_rays = 0
-        shade_ms = raygen_ms = total_ms = 0.0
+        shade_ms = raygen_ms = total_ms = ext_busy_ms = 0.0
+        chains = 1
         nprof = min(8, args.steps)
         for f in frames[args.warmup:args.warmup + nprof]:
             b.trace(f)
             b.sync()
             t = b.last_trace_timing()
             ext_ms += t.extend_ms
+            ext_busy_ms += t.extend_busy_ms
+            chains = t.chains
             ext_launches += t.extend_launches
             prof_rays += t.rays
             shade_ms += t.shade_ms
@@ -168,7 +178,7 @@ def main():
             count_rays += t.rays
         b.set_profiling(0)
         alg_bytes = count_rays * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES
-        achieved = alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        achieved = alg_bytes / (ext_busy_ms * 1e-3) / 1e9 if ext_busy_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
         if args.workload == "sponza_class" and os.path.exists(tpath):
@@ -180,11 +190,13 @@ def main():
             "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4), "launches": ext_launches,
+            "chains": chains, "concurrency": round(ext_ms / ext_busy_ms, 2) if ext_busy_ms > 0 else None,
             "alg_bytes_per_launch": int(alg_bytes / max(1, ext_launches)),
             "bytes_per_ray": round(alg_bytes / max(1, count_rays), 1),
             "nodes_per_ray": round(nodes / max(1, count_rays), 2), "tris_per_ray": round(tris / max(1, count_rays), 2),
-            "frame_ms": {"total": round(total_ms / nprof, 3), "raygen": round(raygen_ms / nprof, 3),
-                         "extend": round(ext_ms / nprof, 3), "shade": round(shade_ms / nprof, 3)},
+            "frame_ms": {"total": round(total_ms / nprof, 3), "raygen_sum": round(raygen_ms / nprof, 3),
+                         "extend_busy": round(ext_busy_ms / nprof, 3), "extend_sum": round(ext_ms / nprof, 3),
+                         "shade_sum": round(shade_ms / nprof, 3)},
         }
 
         # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload ----

@@ -71,16 +71,21 @@ typedef struct pt_params {
 
 typedef struct pt_accel_stats {
     uint32_t num_triangles;
-    uint32_t num_nodes;        /* 4-wide nodes, 128 bytes each */
-    uint32_t max_depth;        /* levels of 4-wide nodes */
+    uint32_t num_nodes;        /* 8-wide nodes, 128 bytes each */
+    uint32_t max_depth;        /* levels of 8-wide nodes */
     uint32_t num_leaves;
     float build_ms;            /* device time of the build kernels */
     float sah_cost;            /* surface-area-heuristic cost of the built hierarchy */
 } pt_accel_stats;
 
-/* per-kernel device time of the last pt_trace (HIP events on the context's stream) */
+/* per-kernel device time of the last pt_trace (HIP events on the streams the kernels run on).
+ * A frame runs as several chains side by side (pt_set_chains), so launches of one kernel overlap:
+ * raygen_ms / extend_ms / shade_ms are sums of the launch durations, extend_busy_ms is the time
+ * during which at least one traversal launch was running, total_ms is first start to last end. */
 typedef struct pt_trace_timing {
     float total_ms, raygen_ms, extend_ms, shade_ms;
+    float extend_busy_ms;
+    uint32_t chains;
     uint32_t extend_launches, shade_launches;   /* launches that had rays queued */
     uint64_t rays;             /* ray segments traced by that call */
     uint64_t nodes_visited;    /* hierarchy nodes fetched / triangles tested by the traversal kernel; */
@@ -134,13 +139,22 @@ int pt_resolve(pt_ctx* ctx);
 int pt_read_primary_ids(pt_ctx* ctx, uint32_t* submesh_prim_pairs);
 /* number of traceRayEXT-equivalents issued since the context was created */
 int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
-/* mode 1: every kernel launch of later pt_trace calls is bracketed by HIP events on the
- * context's stream; pt_last_trace_timing then reports the last frame's per-kernel time.
+/* A frame is traced as `chains` (1, 2, 4 or 8) independent pipelines, each with a share of the
+ * pixel tiles and a HIP stream of its own, so that the tail of one pipeline's traversal launch
+ * overlaps the others' work; images do not depend on the setting.  Chains overlap only if HIP has
+ * a hardware queue for each: the default is 4, or 8 when GPU_MAX_HW_QUEUES >= 8 is in the
+ * environment (HIP reads it when its runtime starts).  No counterpart in the reference, whose
+ * scheduling is the Vulkan driver's. */
+int pt_set_chains(pt_ctx* ctx, uint32_t chains);
+/* mode 1: every kernel launch of later pt_trace calls is bracketed by HIP events on the stream
+ * it runs on, and a profiled frame does not overlap its neighbours; pt_last_trace_timing then
+ * reports the last frame's per-kernel time.
  * mode 2: as 1, and the traversal kernel also counts the nodes and triangles it touches
  * (slower; for the bytes-per-ray figure, not for timing).  mode 0: off. */
 int pt_set_profiling(pt_ctx* ctx, int mode);
 int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out);
-/* the HIP stream pt_trace launches on (hipStream_t as void*) */
+/* the context's main HIP stream (hipStream_t as void*).  Work the caller enqueues on it after this
+ * call runs after every pt_trace issued so far, and later pt_trace calls run after that work. */
 void* pt_stream(pt_ctx* ctx);
 /* device pointers of the images currently rendered into */
 void* pt_device_image(pt_ctx* ctx);

@@ -17,7 +17,7 @@ EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_default_params", "pt_scene_upload", "pt_build_accel",
     "pt_update_materials", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
-    "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_device_image", "pt_device_accum",
+    "pt_set_chains", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_device_image", "pt_device_accum",
     "pt_debug_intersect", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
 ]
 
@@ -35,6 +35,7 @@ class AccelStats(C.Structure):
 
 class TraceTiming(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("raygen_ms", C.c_float), ("extend_ms", C.c_float), ("shade_ms", C.c_float),
+                ("extend_busy_ms", C.c_float), ("chains", C.c_uint32),
                 ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("rays", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
 
@@ -74,6 +75,7 @@ def load_library():
     lib.pt_resolve.argtypes = [vp]
     lib.pt_read_primary_ids.argtypes = [vp, up]
     lib.pt_ray_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.pt_set_chains.argtypes = [vp, C.c_uint32]
     lib.pt_set_profiling.argtypes = [vp, C.c_int]
     lib.pt_last_trace_timing.argtypes = [vp, C.POINTER(TraceTiming)]
     for name in ("pt_stream", "pt_device_image", "pt_device_accum"):
@@ -190,6 +192,10 @@ class Backend:
         v = C.c_uint64()
         self._check(self.lib.pt_ray_count(self.h, C.byref(v)))
         return v.value
+
+    def set_chains(self, chains):
+        """Number of independent pipelines (1, 2, 4 or 8) a frame is split into; images do not depend on it."""
+        self._check(self.lib.pt_set_chains(self.h, int(chains)))
 
     def set_profiling(self, mode):
         """0 off, 1 per-kernel HIP-event timing, 2 timing + traversal node/triangle counters."""

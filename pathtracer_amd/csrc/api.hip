@@ -65,6 +65,7 @@ static int finish_timing(pt_ctx* ctx)
     std::vector<uint32_t> words(chain_words * C);
     PT_HIP(ctx, hipMemcpy(words.data(), ctx->d_counts, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     float first = 0.0f, last = 0.0f;
+    std::vector<std::pair<float, float>> spans;     // traversal launches, ms since chain 0's first event
     for (uint32_t c = 0; c < C; c++) {
         std::vector<hipEvent_t>& ev = ctx->events[c];
         float ms = 0.0f;
@@ -79,6 +80,9 @@ static int finish_timing(pt_ctx* ctx)
             if (queued > 0) {
                 t.extend_ms += e; t.shade_ms += sh;
                 t.extend_launches++; t.shade_launches++;
+                float b0 = 0.0f;
+                PT_HIP(ctx, hipEventElapsedTime(&b0, ctx->events[0][0], ev[1 + 2 * r]));
+                spans.push_back({b0, b0 + e});
             }
             t.rays += queued;
         }
@@ -90,6 +94,13 @@ static int finish_timing(pt_ctx* ctx)
         if (c == 0 || b > last) last = b;
     }
     t.total_ms = last - first;
+    t.chains = C;
+    std::sort(spans.begin(), spans.end());
+    float cur_end = -1e30f;
+    for (auto& sp : spans) {
+        if (sp.first > cur_end) { t.extend_busy_ms += sp.second - sp.first; cur_end = sp.second; }
+        else if (sp.second > cur_end) { t.extend_busy_ms += sp.second - cur_end; cur_end = sp.second; }
+    }
     if (ctx->profiling == 2) {
         unsigned long long hs[16] = {0};
         PT_HIP(ctx, hipMemcpy(hs, ctx->d_stats, 128, hipMemcpyDeviceToHost));
@@ -113,7 +124,7 @@ static int finish_timing(pt_ctx* ctx)
 
 int sync_streams(pt_ctx* ctx)
 {
-    for (uint32_t c = ctx->chains; c-- > 0;)
+    for (uint32_t c = PT_MAX_CHAINS; c-- > 0;)
         if (ctx->chain_stream[c]) PT_HIP(ctx, hipStreamSynchronize(ctx->chain_stream[c]));
     ctx->join_pending = false;
     return PT_OK;
@@ -156,13 +167,18 @@ int pt_create(int device_ordinal, pt_ctx** out)
     pt_default_params(&ctx->params);
     hipError_t es = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     ctx->chain_stream[0] = ctx->stream;
-    uint32_t chains = PT_MAX_CHAINS;
-    if (const char* e = getenv("PT_CHAINS")) chains = (uint32_t)atoi(e);
-    if (chains < 1 || chains > PT_MAX_CHAINS || PT_SHARDS % chains) chains = PT_MAX_CHAINS;
-    ctx->chains = chains;
-    for (uint32_t c = 1; c < chains && es == hipSuccess; c++) {
+    for (uint32_t c = 1; c < PT_MAX_CHAINS && es == hipSuccess; c++) {
         es = hipStreamCreateWithFlags(&ctx->chain_stream[c], hipStreamNonBlocking);
         if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming);
+    }
+    // Chains only overlap when each has a hardware queue of its own: HIP gives a process 4 unless
+    // GPU_MAX_HW_QUEUES (read when the runtime starts) says otherwise.
+    uint32_t hwq = 4;
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = (uint32_t)atoi(e);
+    ctx->chains = hwq >= 8 ? 8u : 4u;
+    if (const char* e = getenv("PT_CHAINS")) {
+        uint32_t c = (uint32_t)atoi(e);
+        if (c >= 1 && c <= PT_MAX_CHAINS && PT_SHARDS % c == 0) ctx->chains = c;
     }
     if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
     hipError_t e1 = hipMalloc((void**)&ctx->d_total_rays, 8);
@@ -375,6 +391,21 @@ int pt_set_params(pt_ctx* ctx, const pt_params* p)
     if (p->spp_per_frame > 0xFFFFu || p->max_bounces > 0xFFFFu || (uint64_t)p->spp_per_frame * p->max_bounces > 65536ull)
         return set_error(ctx, PT_ERR_TOO_LARGE, "spp_per_frame * max_bounces must not exceed 65536");
     ctx->params = *p;
+    return PT_OK;
+}
+
+int pt_set_chains(pt_ctx* ctx, uint32_t chains)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (chains < 1 || chains > PT_MAX_CHAINS || PT_SHARDS % chains)
+        return set_error(ctx, PT_ERR_INVALID, "pt_set_chains: chains must be 1, 2, 4 or 8");
+    PT_SYNC(ctx);
+    if (ctx->timing_pending) {
+        int rc = finish_timing(ctx);
+        if (rc) return rc;
+    }
+    ctx->chains = chains;
+    ctx->main_dirty = true;
     return PT_OK;
 }
 

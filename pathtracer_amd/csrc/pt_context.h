@@ -17,8 +17,8 @@ struct pt_ctx {
     // one chain's traversal launch then overlaps the other chains' work.  Chains are not joined at the end of
     // pt_trace: consecutive frames flow through each chain back to back; anything that reads results joins first.
     uint32_t chains = 1;
-    hipStream_t chain_stream[PT_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t chain_done[PT_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t chain_stream[PT_MAX_CHAINS] = {};
+    hipEvent_t chain_done[PT_MAX_CHAINS] = {};
     hipEvent_t fork_event = nullptr;
     bool main_dirty = true;      // the main stream got work the other chains have not yet been ordered after
     bool join_pending = false;   // the other chains got work the main stream has not yet been ordered after

@@ -36,7 +36,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(TextureDesc) == 24
     assert C.sizeof(SceneDesc) == 8 * 8 + 6 * 4
     assert C.sizeof(backend.AccelStats) == 24
-    assert C.sizeof(backend.TraceTiming) == 48
+    assert C.sizeof(backend.TraceTiming) == 56
 
 
 def test_default_params_are_the_reference_constants():

@@ -260,6 +260,29 @@ def test_cornell_frames_bit_exact(backend, cornell, cameras, W, H, S, B, frames)
     assert_same_frame(backend, o, rays)
 
 
+@pytest.mark.parametrize("chains", [1, 2, 8])
+def test_image_does_not_depend_on_the_chain_count(backend, cornell, cameras, chains):
+    """Frames issued back to back (no synchronisation between them) with the frame split into 1, 2 or 8
+    independent pipelines: same bits as the oracle, hence as each other.  72x40 leaves some shards of the
+    ray queue without a tile, 8 chains then have empty pipelines."""
+    try:
+        backend.set_chains(chains)
+        for W, H in ((72, 40), (256, 256)):
+            o, rays = render_pair(backend, cornell, cameras["512x512"], W, H, (1, 2, 3, 4, 5), spp_per_frame=2, max_bounces=5)
+            assert_same_frame(backend, o, rays)
+        t_before = backend.ray_count()
+        backend.set_profiling(1)
+        backend.trace(6)
+        t = backend.last_trace_timing()
+        backend.set_profiling(0)
+        assert t.chains == chains and t.rays == backend.ray_count() - t_before
+        assert 0 < t.extend_busy_ms <= t.extend_ms * 1.001 and t.extend_busy_ms <= t.total_ms * 1.001
+    finally:
+        backend.set_chains(4)
+    with pytest.raises(BackendError):
+        backend.set_chains(3)
+
+
 def test_cornell_512_config_and_golden_ids(backend, cornell, cameras):
     # BASELINE configs[0]: Cornell 512x512, 1 spp, 4 bounces
     o, rays = render_pair(backend, cornell, cameras["512x512"], 512, 512, (1, 2), spp_per_frame=1, max_bounces=4)
