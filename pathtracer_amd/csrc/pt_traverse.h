@@ -9,8 +9,12 @@
 // Execution: a wave keeps 64 traversals in flight.  Rays differ widely in length, so a wave that
 // waited for its longest ray would idle most lanes; instead, whenever PT_REFILL_MIN lanes are free
 // the wave takes that many new rays from its queue with one atomic and carries on (dynamic ray
-// fetch).  Node steps and leaf steps are separate phases: lanes that reached a leaf wait until
-// enough lanes have one (or nobody has a node left), so the triangle code runs with fuller waves.
+// fetch).  Node steps and triangle tests are separate phases.  A lane that reaches a leaf parks it
+// in a pending slot and walks on through its stack; once PT_LEAF_MIN lanes have a pending leaf
+// (or nobody has a node left) the wave runs the triangle phase, in which the pending triangles of
+// all lanes are dealt out one per lane, whichever lane owns the ray: leaves hold 1..4 triangles
+// and only some lanes have one, so testing them in the owning lane would run the triangle code
+// mostly empty.  The ray travels to the testing lane, and the result back, through lane permutes.
 //
 // Stack: the top PT_STACK_LDS entries of each lane live in an LDS ring (one column per lane,
 // conflict free); deeper entries move in blocks to a per-wave spill area in global memory, laid
@@ -32,13 +36,14 @@ namespace ptd {
 #define PT_REFILL_MIN 20   // free lanes that trigger a refill
 #endif
 #ifndef PT_LEAF_MIN
-#define PT_LEAF_MIN 16     // lanes holding a leaf that trigger the triangle phase while others still walk nodes
+#define PT_LEAF_MIN 24     // lanes with a pending leaf that trigger the triangle phase while others still walk nodes
 #endif
+#define PT_CUR_NONE 0x7FFFFFFFu   // s.cur when the stack ran empty; node indices are below, leaf references above
+#define PT_OWNER_BYTES 256        // LDS bytes per wave for the triangle phase's work list
 
 struct HitRec {
     float t, u, v;
     uint32_t tri;          // index into the TriRec array, 0xFFFFFFFF = miss
-    uint32_t submesh, prim;
 };
 
 // what one wave did during a launch (statistics builds only); times are wall_clock64() ticks (10 ns)
@@ -74,8 +79,9 @@ PT_DEV RayPre ray_precompute(v3 d)
     return p;
 }
 
-// true when the ray hits with t > tmin; fills t,u,v (u,v = weights of vertex 1 and 2)
-PT_DEV bool tri_test(const RayPre& r, v3 o, v3 v0, v3 v1, v3 v2, float tmin, float& t, float& u, float& v)
+// true when the ray hits with t > tmin; fills t and V, W, det: the barycentric weights of vertex 1 and 2
+// are V / det and W / det, divided out only for the hit that is finally reported
+PT_DEV bool tri_test(const RayPre& r, v3 o, v3 v0, v3 v1, v3 v2, float tmin, float& t, float& oV, float& oW, float& odet)
 {
     v3 A = v0 - o, B = v1 - o, C = v2 - o;
     float Akz = comp(A, r.kz), Bkz = comp(B, r.kz), Ckz = comp(C, r.kz);
@@ -101,8 +107,7 @@ PT_DEV bool tri_test(const RayPre& r, v3 o, v3 v0, v3 v1, v3 v2, float tmin, flo
     float tt = fdiv(T, det);
     if (!(tt > tmin)) return false;
     t = tt;
-    u = fdiv(V, det);
-    v = fdiv(W, det);
+    oV = V; oW = W; odet = det;
     return true;
 }
 
@@ -116,7 +121,10 @@ struct Trav {
     float ofx, ofy, ofz;           // -(o * idir) + slack : far planes
     bool negx, negy, negz;         // direction signs: pick which quantised plane of a child box is the near one
     HitRec best;
-    uint32_t cur;                  // node index, or leaf reference (bit 31)
+    float bV, bW, bdet;            // best.u = bV / bdet, best.v = bW / bdet, divided when the ray is finished
+    uint32_t cur;                  // node index, leaf reference (bit 31), or PT_CUR_NONE
+    float cur_key;                 // entry distance of cur
+    uint32_t pend;                 // leaf reference waiting for the triangle phase, 0 = none
     int sp, base;                  // stack depth; entries below base are in the spill area
 };
 
@@ -140,8 +148,11 @@ PT_DEV void trav_init(Trav& s, v3 o, v3 d, float tmin, float tmax)
     s.negy = s.idy < 0.0f;
     s.negz = s.idz < 0.0f;
     s.best.t = tmax; s.best.u = 0.0f; s.best.v = 0.0f;
-    s.best.tri = 0xFFFFFFFFu; s.best.submesh = 0xFFFFFFFFu; s.best.prim = 0xFFFFFFFFu;
+    s.best.tri = 0xFFFFFFFFu;
+    s.bV = 0.0f; s.bW = 0.0f; s.bdet = 1.0f;
     s.cur = 0;
+    s.cur_key = tmin;
+    s.pend = 0;
     s.sp = 0;
     s.base = 0;
 }
@@ -167,7 +178,7 @@ PT_DEV void stack_reserve(Trav& s, const uint2* lds_stack, int stride, uint2* ov
         s.sp++;                                                                             \
     }
 
-// pops until an entry that can still hold a closer hit; false when the stack is empty (ray finished)
+// pops until an entry that can still hold a closer hit; false (and cur = PT_CUR_NONE) when the stack is empty
 PT_DEV bool trav_pop(Trav& s, uint2* lds_stack, int stride, const uint2* ovf)
 {
     while (s.sp > 0) {
@@ -178,8 +189,9 @@ PT_DEV bool trav_pop(Trav& s, uint2* lds_stack, int stride, const uint2* ovf)
         }
         s.sp--;
         uint2 e = lds_stack[(s.sp & (PT_STACK_LDS - 1)) * stride];
-        if (u2f(e.y) <= s.best.t) { s.cur = e.x; return true; }
+        if (u2f(e.y) <= s.best.t) { s.cur = e.x; s.cur_key = u2f(e.y); return true; }
     }
+    s.cur = PT_CUR_NONE;
     return false;
 }
 
@@ -242,41 +254,100 @@ PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack
     for (int j = 7; j >= 1; j--) {
         if (key[j] < PT_KEY_MISS) PT_PUSH(pick_child(c03, c47, key[j] & 7u), u2f(key[j] & 0x7ffffff8u))
     }
-    if (key[0] < PT_KEY_MISS) { s.cur = pick_child(c03, c47, key[0] & 7u); return true; }
+    if (key[0] < PT_KEY_MISS) { s.cur = pick_child(c03, c47, key[0] & 7u); s.cur_key = u2f(key[0] & 0x7ffffff8u); return true; }
     return trav_pop(s, lds_stack, stride, ovf);
 }
 
-// one leaf: tests its (up to 4) triangles, then pops
-template <bool STATS>
-PT_DEV bool leaf_step(Trav& s, const TriRec* __restrict__ tris, uint2* lds_stack, int stride, const uint2* ovf, uint32_t& stat_tris)
+// lanes below this one among the set bits of mask
+PT_DEV uint32_t lanes_below(unsigned long long mask)
 {
-    uint32_t first = s.cur & 0x0FFFFFFFu;
-    uint32_t cnt = ((s.cur >> 28) & 7u) + 1u;
-    for (uint32_t i = 0; i < cnt; i++) {
-        const float4* tp = reinterpret_cast<const float4*>(tris + first + i);
-        float4 a = tp[0], b = tp[1], c = tp[2];
-        if (STATS) stat_tris++;
-        float t, u, v;
-        if (!tri_test(s.rp, s.o, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), s.tmin, t, u, v)) continue;
-        if (!(t < s.tmax)) continue;
-        uint32_t sm = f2u(a.w), pr = f2u(b.w);
-        bool take = t < s.best.t ||
-                    (t == s.best.t && s.best.tri != 0xFFFFFFFFu && (sm < s.best.submesh || (sm == s.best.submesh && pr < s.best.prim)));
-        if (take) {
-            s.best.t = t; s.best.u = u; s.best.v = v;
-            s.best.tri = first + i; s.best.submesh = sm; s.best.prim = pr;
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+PT_DEV float lane_read(float v, uint32_t src_lane) { return u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)f2u(v))); }
+PT_DEV uint32_t lane_read(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+
+// at equal t the smaller (submesh, primitive) wins; both records are read only in that rare case
+PT_DEV bool wins_tie(const TriRec* __restrict__ tris, uint32_t cand, uint32_t best)
+{
+    uint32_t cs = tris[cand].submesh, cp = tris[cand].prim, bs = tris[best].submesh, bp = tris[best].prim;
+    return cs < bs || (cs == bs && cp < bp);
+}
+
+// Triangle phase, run by the whole wave.  Every lane with a pending leaf owns 1..4 work items (its
+// triangles); the items are numbered through the wave and item j is tested by lane j % 64 in pass
+// j / 64, with the owner's ray fetched by lane permutes.  The owner then collects the distances of
+// its items, keeps the closest under the usual rules, and fetches that one's barycentric terms.
+// `owner` is this wave's PT_OWNER_BYTES-byte LDS work list.  Must be called in wave-uniform control flow.
+template <bool STATS>
+PT_DEV void leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, uint8_t* owner, uint32_t lane, uint32_t& stat_tris)
+{
+    const uint32_t first = s.pend & 0x0FFFFFFFu;
+    const uint32_t cnt = has_pend ? ((s.pend >> 28) & 7u) + 1u : 0u;
+    // exclusive prefix sum of cnt (0..4) over the lanes, from three ballots
+    unsigned long long b0 = __ballot((cnt & 1u) != 0), b1 = __ballot((cnt & 2u) != 0), b2 = __ballot((cnt & 4u) != 0);
+    const uint32_t off = lanes_below(b0) + 2u * lanes_below(b1) + 4u * lanes_below(b2);
+    const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+        if (k < cnt) owner[off + k] = (uint8_t)(lane | (k << 6));
+    __syncthreads();
+    const uint32_t kpack = (uint32_t)s.rp.kx | ((uint32_t)s.rp.ky << 2) | ((uint32_t)s.rp.kz << 4);
+    for (uint32_t p0 = 0; p0 < total; p0 += 64u) {
+        // ---- test item p0 + lane
+        const uint32_t j = p0 + lane;
+        const bool work = j < total;
+        const uint32_t ow = work ? owner[j] : lane;
+        const uint32_t src = ow & 63u, k = ow >> 6;
+        const uint32_t w_first = lane_read(first, src);
+        v3 wo = V3(lane_read(s.o.x, src), lane_read(s.o.y, src), lane_read(s.o.z, src));
+        RayPre wr;
+        wr.Sx = lane_read(s.rp.Sx, src); wr.Sy = lane_read(s.rp.Sy, src); wr.Sz = lane_read(s.rp.Sz, src);
+        const uint32_t wk = lane_read(kpack, src);
+        wr.kx = (int)(wk & 3u); wr.ky = (int)((wk >> 2) & 3u); wr.kz = (int)(wk >> 4);
+        const float w_tmin = lane_read(s.tmin, src);
+        float wt = __builtin_inff(), wV = 0.0f, wW = 0.0f, wdet = 1.0f;
+        if (work) {
+            const float4* tp = reinterpret_cast<const float4*>(tris + w_first + k);
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            if (STATS) stat_tris++;
+            float t, V, W, det;
+            if (tri_test(wr, wo, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), w_tmin, t, V, W, det)) { wt = t; wV = V; wW = W; wdet = det; }
         }
+        // ---- owners collect
+        uint32_t win = lane;
+        bool won = false;
+#pragma unroll
+        for (uint32_t kk = 0; kk < 4; kk++) {
+            const uint32_t jj = off + kk;
+            const float tk = lane_read(wt, jj & 63u);
+            if (kk < cnt && (jj - p0) < 64u && tk < s.tmax) {
+                bool take = tk < s.best.t;
+                if (tk == s.best.t && s.best.tri != 0xFFFFFFFFu) take = wins_tie(tris, first + kk, s.best.tri);
+                if (take) { s.best.t = tk; s.best.tri = first + kk; win = jj & 63u; won = true; }
+            }
+        }
+        const float gV = lane_read(wV, win), gW = lane_read(wW, win), gdet = lane_read(wdet, win);
+        if (won) { s.bV = gV; s.bW = gW; s.bdet = gdet; }
     }
-    return trav_pop(s, lds_stack, stride, ovf);
+    __syncthreads();
+}
+
+PT_DEV void finish_hit(Trav& s)
+{
+    if (s.best.tri != 0xFFFFFFFFu) {
+        s.best.u = fdiv(s.bV, s.bdet);
+        s.best.v = fdiv(s.bW, s.bdet);
+    }
 }
 
 // Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue, emit(i, hit) stores
 // its result; *cursor hands out queue indices (must be 0 at launch), n = queue length.
 // lds_stack points at this lane's column: entry k is lds_stack[k * stride]; ovf points at this lane's
-// column of the wave's global spill area: entry k is ovf[k * 64].
+// column of the wave's global spill area: entry k is ovf[k * 64]; owner is the wave's LDS work list.
 template <bool STATS, class Fetch, class Emit>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
-                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, Fetch fetch, Emit emit,
+                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint8_t* owner, Fetch fetch, Emit emit,
                        uint32_t& stat_nodes, uint32_t& stat_tris, WaveStats* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -284,7 +355,8 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
     bool has = false;
     bool exhausted = false;      // wave-uniform
     uint32_t my = 0;
-    s.cur = 0;
+    s.cur = PT_CUR_NONE;
+    s.pend = 0;
     unsigned long long t_start = 0, t_exh = 0;
     uint32_t ray_steps = 0, ray_steps_max = 0;
     if (STATS && wave_stats) t_start = wall_clock64();
@@ -297,7 +369,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
             if (lane == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(cursor, nidle);
             base = __shfl(base, __ffsll((long long)idle) - 1);
             if (!has) {
-                uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                uint32_t i = base + lanes_below(idle);
                 if (i < n) {
                     v3 o, d;
                     float tmin, tmax;
@@ -319,7 +391,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
             continue;
         }
         // node phase: every lane standing on an internal node takes one step
-        bool at_node = has && !(s.cur & PT_CHILD_LEAF);
+        bool at_node = has && s.cur < PT_CUR_NONE;
         if (STATS && wave_stats) {
             unsigned long long nm = __ballot(at_node);
             if (lane == 0 && nm) { wave_stats->node_phases++; wave_stats->node_lanes += (uint32_t)__popcll(nm); }
@@ -327,16 +399,30 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         if (STATS && has) { ray_steps++; ray_steps_max = max(ray_steps_max, ray_steps); }
         if (at_node) {
             if (STATS) stat_nodes++;
-            if (!node_step(s, nodes, lds_stack, stride, ovf)) { emit(my, s.best); has = false; }
+            node_step(s, nodes, lds_stack, stride, ovf);
         }
-        // triangle phase: once enough lanes hold a leaf, or nobody is left on a node
-        bool at_leaf = has && (s.cur & PT_CHILD_LEAF);
-        unsigned long long leafm = __ballot(at_leaf);
-        unsigned long long nodem = __ballot(has && !(s.cur & PT_CHILD_LEAF));
-        if (leafm != 0 && ((uint32_t)__popcll(leafm) >= PT_LEAF_MIN || nodem == 0)) {
-            if (STATS && wave_stats && lane == 0) { wave_stats->leaf_phases++; wave_stats->leaf_lanes += (uint32_t)__popcll(leafm); }
-            if (at_leaf) {
-                if (!leaf_step<STATS>(s, tris, lds_stack, stride, ovf, stat_tris)) { emit(my, s.best); has = false; }
+        // a leaf goes to the pending slot and the lane walks on; with the slot taken the lane waits on the leaf
+        if (has && s.cur > PT_CUR_NONE && s.pend == 0) {
+            s.pend = s.cur;
+            trav_pop(s, lds_stack, stride, ovf);
+        }
+        if (has && s.cur == PT_CUR_NONE && s.pend == 0) { finish_hit(s); emit(my, s.best); has = false; }
+        // triangle phase: once enough lanes hold a pending leaf, or nobody is left on a node
+        bool has_pend = has && s.pend != 0;
+        unsigned long long pendm = __ballot(has_pend);
+        unsigned long long nodem = __ballot(has && s.cur < PT_CUR_NONE);
+        if (pendm != 0 && ((uint32_t)__popcll(pendm) >= PT_LEAF_MIN || nodem == 0)) {
+            if (STATS && wave_stats && lane == 0) { wave_stats->leaf_phases++; wave_stats->leaf_lanes += (uint32_t)__popcll(pendm); }
+            leaf_phase<STATS>(s, has_pend, tris, owner, lane, stat_tris);
+            if (has_pend) {
+                s.pend = 0;
+                // the hit may have come closer than the subtree this lane went on to meanwhile
+                if (s.cur != PT_CUR_NONE && s.cur_key > s.best.t) trav_pop(s, lds_stack, stride, ovf);
+                if (s.cur > PT_CUR_NONE) {
+                    s.pend = s.cur;
+                    trav_pop(s, lds_stack, stride, ovf);
+                }
+                if (s.cur == PT_CUR_NONE && s.pend == 0) { finish_hit(s); emit(my, s.best); has = false; }
             }
         }
     }

@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, 
                                                        unsigned long long* stats, unsigned long long* wave_trace)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
+    __shared__ uint8_t owner[PT_OWNER_BYTES];
     const uint32_t ls = blockIdx.x % nshards;
     const uint32_t n = counts[ls];
     const uint32_t base = (shard0 + ls) * shard_cap;
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, 
     WaveStats ws;
     trace_wave<STATS>(
         sc.nodes, sc.tris, sc.num_tris, n, &cursors[ls], stack + threadIdx.x, EXT_BLOCK,
-        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x,
+        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rayO[base + i], rd = rayD[base + i];
             o = V3(ro.x, ro.y, ro.z);
@@ -603,10 +604,11 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
                                                                 uint32_t* __restrict__ out, uint2* spill, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
+    __shared__ uint8_t owner[PT_OWNER_BYTES];
     uint32_t sn = 0, st = 0;
     trace_wave<true>(
         sc.nodes, sc.tris, sc.num_tris, n, cursor, stack + threadIdx.x, EXT_BLOCK,
-        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x,
+        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rays[2 * i], rd = rays[2 * i + 1];
             o = V3(ro.x, ro.y, ro.z);
@@ -617,7 +619,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
         [&](uint32_t i, const HitRec& h) {
             uint32_t* o = out + (size_t)i * 5;
             if (h.tri == MISS) { o[0] = f2u(h.t); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }   // h.t is still tmax
-            else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = h.submesh; o[4] = h.prim; }
+            else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = sc.tris[h.tri].submesh; o[4] = sc.tris[h.tri].prim; }
         }, sn, st);
     atomicAdd(&stats[0], (unsigned long long)sn);
     atomicAdd(&stats[1], (unsigned long long)st);
