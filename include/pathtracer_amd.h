@@ -78,10 +78,11 @@ typedef struct pt_accel_stats {
     float sah_cost;            /* surface-area-heuristic cost of the built hierarchy */
 } pt_accel_stats;
 
-/* per-kernel device time of the last pt_trace (HIP events on the streams the kernels run on).
- * A frame runs as several chains side by side (pt_set_chains), so launches of one kernel overlap:
- * raygen_ms / extend_ms / shade_ms are sums of the launch durations, extend_busy_ms is the time
- * during which at least one traversal launch was running, total_ms is first start to last end. */
+/* per-kernel device time of the frames traced since the previous read-out (HIP events on the
+ * streams the kernels run on).  A frame runs as several chains side by side (pt_set_chains) and
+ * consecutive frames overlap, so launches of one kernel overlap: raygen_ms / extend_ms / shade_ms
+ * are sums of the launch durations, extend_busy_ms is the time during which at least one
+ * traversal launch was running, total_ms is first start to last end. */
 typedef struct pt_trace_timing {
     float total_ms, raygen_ms, extend_ms, shade_ms;
     float extend_busy_ms;
@@ -147,8 +148,8 @@ int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
  * scheduling is the Vulkan driver's. */
 int pt_set_chains(pt_ctx* ctx, uint32_t chains);
 /* mode 1: every kernel launch of later pt_trace calls is bracketed by HIP events on the stream
- * it runs on, and a profiled frame does not overlap its neighbours; pt_last_trace_timing then
- * reports the last frame's per-kernel time.
+ * it runs on; pt_last_trace_timing waits for the frames issued so far and reports their
+ * per-kernel time, summed since its previous call (or since the mode was set).
  * mode 2: as 1, and the traversal kernel also counts the nodes and triangles it touches
  * (slower; for the bytes-per-ray figure, not for timing).  mode 0: off. */
 int pt_set_profiling(pt_ctx* ctx, int mode);

@@ -54,26 +54,23 @@ static int upload(pt_ctx* ctx, T*& dst, const T* src, size_t n)
     return PT_OK;
 }
 
-static int finish_timing(pt_ctx* ctx)
+int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
 {
-    if (!ctx->timing_pending) return PT_OK;
-    ctx->timing_pending = false;
-    pt_trace_timing t{};
-    const uint32_t R = ctx->timing_rounds, C = ctx->timing_chains, spc = PT_SHARDS / C;
-    // device-side queue sizes tell which rounds had work
+    if (!slot.pending) return PT_OK;
+    slot.pending = false;
+    pt_trace_timing& t = ctx->timing;
+    const uint32_t R = slot.rounds, C = slot.chains, spc = PT_SHARDS / C;
     const size_t chain_words = (size_t)2 * (R + 1) * spc;
-    std::vector<uint32_t> words(chain_words * C);
-    PT_HIP(ctx, hipMemcpy(words.data(), ctx->d_counts, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    float first = 0.0f, last = 0.0f;
-    std::vector<std::pair<float, float>> spans;     // traversal launches, ms since chain 0's first event
+    for (uint32_t c = 0; c < C; c++) PT_HIP(ctx, hipEventSynchronize(slot.ev[c][2 + 2 * R]));
     for (uint32_t c = 0; c < C; c++) {
-        std::vector<hipEvent_t>& ev = ctx->events[c];
+        std::vector<hipEvent_t>& ev = slot.ev[c];
         float ms = 0.0f;
         PT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
         t.raygen_ms += ms;
         for (uint32_t r = 0; r < R; r++) {
+            // the frame's queue sizes tell which rounds had work
             uint64_t queued = 0;
-            for (uint32_t k = 0; k < spc; k++) queued += words[c * chain_words + (size_t)r * spc + k];
+            for (uint32_t k = 0; k < spc; k++) queued += slot.h_counts[c * chain_words + (size_t)r * spc + k];
             float e = 0.0f, sh = 0.0f;
             PT_HIP(ctx, hipEventElapsedTime(&e, ev[1 + 2 * r], ev[2 + 2 * r]));
             PT_HIP(ctx, hipEventElapsedTime(&sh, ev[2 + 2 * r], ev[3 + 2 * r]));
@@ -81,34 +78,49 @@ static int finish_timing(pt_ctx* ctx)
                 t.extend_ms += e; t.shade_ms += sh;
                 t.extend_launches++; t.shade_launches++;
                 float b0 = 0.0f;
-                PT_HIP(ctx, hipEventElapsedTime(&b0, ctx->events[0][0], ev[1 + 2 * r]));
-                spans.push_back({b0, b0 + e});
+                PT_HIP(ctx, hipEventElapsedTime(&b0, ctx->prof_ref, ev[1 + 2 * r]));
+                ctx->ext_spans.push_back({b0, b0 + e});
             }
             t.rays += queued;
         }
-        // frame time: first chain start to last chain end, both measured from chain 0's first event
         float a = 0.0f, b = 0.0f;
-        if (c > 0) PT_HIP(ctx, hipEventElapsedTime(&a, ctx->events[0][0], ev[0]));
-        PT_HIP(ctx, hipEventElapsedTime(&b, ctx->events[0][0], ev[2 + 2 * R]));
-        if (c == 0 || a < first) first = a;
-        if (c == 0 || b > last) last = b;
+        PT_HIP(ctx, hipEventElapsedTime(&a, ctx->prof_ref, ev[0]));
+        PT_HIP(ctx, hipEventElapsedTime(&b, ctx->prof_ref, ev[2 + 2 * R]));
+        if (t.chains == 0 || a < ctx->win_first) ctx->win_first = a;
+        if (t.chains == 0 || b > ctx->win_last) ctx->win_last = b;
+        t.chains = C;
     }
-    t.total_ms = last - first;
-    t.chains = C;
-    std::sort(spans.begin(), spans.end());
+    return PT_OK;
+}
+
+// collects every frame still in flight and closes the timing window: totals into ctx->timing
+static int finish_timing(pt_ctx* ctx)
+{
+    if (!ctx->window_open) return PT_OK;
+    for (uint32_t k = 0; k < PT_PROF_SLOTS; k++) {
+        int rc = collect_slot(ctx, ctx->prof_slot[(ctx->prof_next + k) % PT_PROF_SLOTS]);
+        if (rc) return rc;
+    }
+    ctx->window_open = false;
+    pt_trace_timing& t = ctx->timing;
+    t.total_ms = ctx->win_last - ctx->win_first;
+    std::sort(ctx->ext_spans.begin(), ctx->ext_spans.end());
     float cur_end = -1e30f;
-    for (auto& sp : spans) {
+    t.extend_busy_ms = 0.0f;
+    for (auto& sp : ctx->ext_spans) {
         if (sp.first > cur_end) { t.extend_busy_ms += sp.second - sp.first; cur_end = sp.second; }
         else if (sp.second > cur_end) { t.extend_busy_ms += sp.second - cur_end; cur_end = sp.second; }
     }
+    ctx->ext_spans.clear();
     if (ctx->profiling == 2) {
+        PT_SYNC(ctx);
         unsigned long long hs[16] = {0};
         PT_HIP(ctx, hipMemcpy(hs, ctx->d_stats, 128, hipMemcpyDeviceToHost));
         t.nodes_visited = hs[0];
         t.tris_tested = hs[1];
         if (getenv("PT_WAVE_STATS"))
-            fprintf(stderr, "wave stats: node phases %llu (lanes %llu, %.1f/64), leaf phases %llu (lanes %llu, %.1f/64), refills %llu, wave ms: draining %.1f of resident %.1f, longest ray %llu steps\n",
-                    hs[3], hs[4], hs[3] ? (double)hs[4] / hs[3] : 0.0, hs[5], hs[6], hs[5] ? (double)hs[6] / hs[5] : 0.0, hs[7], hs[8] * 1e-5, hs[9] * 1e-5, hs[10]);
+            fprintf(stderr, "wave stats: node phases %llu (lanes %llu, %.1f/64), leaf phases %llu (lanes %llu, %.1f/64), refills %llu, wave ms: draining %.1f of resident %.1f, longest ray %llu steps; node phases by active lanes <=8: %llu, <=16: %llu, <=32: %llu, <=64: %llu\n",
+                    hs[3], hs[4], hs[3] ? (double)hs[4] / hs[3] : 0.0, hs[5], hs[6], hs[5] ? (double)hs[6] / hs[5] : 0.0, hs[7], hs[8] * 1e-5, hs[9] * 1e-5, hs[10], hs[11], hs[12], hs[13], hs[14]);
         const char* path = getenv("PT_WAVE_TRACE");
         if (path && ctx->d_wave_trace) {
             size_t len = (size_t)ctx->wave_trace_rounds * ctx->wave_trace_waves * 4;
@@ -118,7 +130,6 @@ static int finish_timing(pt_ctx* ctx)
             if (FILE* f = fopen(path, "wb")) { fwrite(buf.data(), sizeof(unsigned long long), buf.size(), f); fclose(f); }
         }
     }
-    ctx->timing = t;
     return PT_OK;
 }
 
@@ -202,8 +213,12 @@ void pt_destroy(pt_ctx* ctx)
     (void)dev_free(ctx->d_wave_trace);
     (void)dev_free(ctx->d_total_rays);
     (void)dev_free(ctx->d_stats);
-    for (auto& v : ctx->events)
-        for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    for (pt_prof_slot& slot : ctx->prof_slot) {
+        for (auto& v : slot.ev)
+            for (hipEvent_t e : v) (void)hipEventDestroy(e);
+        if (slot.h_counts) (void)hipHostFree(slot.h_counts);
+    }
+    if (ctx->prof_ref) (void)hipEventDestroy(ctx->prof_ref);
     for (uint32_t c = 1; c < PT_MAX_CHAINS; c++) {
         if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
         if (ctx->chain_stream[c]) (void)hipStreamDestroy(ctx->chain_stream[c]);
@@ -400,7 +415,7 @@ int pt_set_chains(pt_ctx* ctx, uint32_t chains)
     if (chains < 1 || chains > PT_MAX_CHAINS || PT_SHARDS % chains)
         return set_error(ctx, PT_ERR_INVALID, "pt_set_chains: chains must be 1, 2, 4 or 8");
     PT_SYNC(ctx);
-    if (ctx->timing_pending) {
+    {
         int rc = finish_timing(ctx);
         if (rc) return rc;
     }
@@ -413,11 +428,8 @@ int pt_set_profiling(pt_ctx* ctx, int mode)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (mode < 0 || mode > 2) return set_error(ctx, PT_ERR_INVALID, "pt_set_profiling: mode must be 0, 1 or 2");
-    if (ctx->timing_pending) {
-        PT_SYNC(ctx);
-        int rc = finish_timing(ctx);
-        if (rc) return rc;
-    }
+    int rc = finish_timing(ctx);
+    if (rc) return rc;
     ctx->profiling = mode;
     return PT_OK;
 }
@@ -437,11 +449,6 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (size_t)2 * (rounds + 1) * PT_SHARDS * sizeof(uint32_t)));
         ctx->counts_cap = rounds + 1;
     }
-    if (ctx->timing_pending) {   // a profiled frame is still in flight: collect it before its events are reused
-        PT_SYNC(ctx);
-        int rc = finish_timing(ctx);
-        if (rc) return rc;
-    }
     return launch_trace(ctx, frame_index);
 }
 
@@ -449,7 +456,7 @@ int pt_sync(pt_ctx* ctx)
 {
     if (!ctx) return PT_ERR_INVALID;
     PT_SYNC(ctx);
-    return finish_timing(ctx);
+    return PT_OK;
 }
 
 static int read_back(pt_ctx* ctx, void* host, const void* dev, size_t bytes)
@@ -459,7 +466,7 @@ static int read_back(pt_ctx* ctx, void* host, const void* dev, size_t bytes)
     PT_SYNC(ctx);    // every chain, not only the main stream the copy runs on
     PT_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PT_SYNC(ctx);
-    return finish_timing(ctx);
+    return PT_OK;
 }
 
 int pt_read_image(pt_ctx* ctx, float* rgba) { return ctx ? read_back(ctx, rgba, ctx->d_image, (size_t)ctx->width * ctx->height * 16) : PT_ERR_INVALID; }
@@ -492,17 +499,14 @@ int pt_ray_count(pt_ctx* ctx, uint64_t* rays)
     PT_HIP(ctx, hipMemcpyAsync(&v, ctx->d_total_rays, 8, hipMemcpyDeviceToHost, ctx->stream));
     PT_SYNC(ctx);
     *rays = v;
-    return finish_timing(ctx);
+    return PT_OK;
 }
 
 int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out)
 {
     if (!ctx || !out) return PT_ERR_INVALID;
-    if (ctx->timing_pending) {
-        PT_SYNC(ctx);
-        int rc = finish_timing(ctx);
-        if (rc) return rc;
-    }
+    int rc = finish_timing(ctx);
+    if (rc) return rc;
     *out = ctx->timing;
     return PT_OK;
 }

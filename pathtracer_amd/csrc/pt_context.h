@@ -4,7 +4,18 @@
 #include "pt_types.h"
 #include <hip/hip_runtime.h>
 #include <string>
+#include <utility>
 #include <vector>
+
+// events and queue sizes of one profiled frame; a few are kept so that profiled frames overlap like unprofiled ones
+struct pt_prof_slot {
+    std::vector<hipEvent_t> ev[PT_MAX_CHAINS];
+    uint32_t* h_counts = nullptr;     // pinned copy of the frame's queue sizes
+    size_t h_words = 0;
+    uint32_t rounds = 0, chains = 0;
+    bool pending = false;
+};
+#define PT_PROF_SLOTS 4
 
 struct pt_ctx {
     int device = 0;
@@ -74,13 +85,15 @@ struct pt_ctx {
     float camera[80];
     bool camera_set = false;
 
-    // per-kernel timing of the last frame
+    // per-kernel timing of the frames traced since the last read-out (the timing window)
     int profiling = 0;           // 0 off, 1 events, 2 events + traversal counters
-    std::vector<hipEvent_t> events[PT_MAX_CHAINS];
-    uint32_t timing_chains = 0;
-    pt_trace_timing timing{};
-    uint32_t timing_rounds = 0;
-    bool timing_pending = false;
+    pt_prof_slot prof_slot[PT_PROF_SLOTS];
+    uint32_t prof_next = 0;
+    hipEvent_t prof_ref = nullptr;                    // time zero of the window, on the main stream
+    bool window_open = false;
+    pt_trace_timing timing{};                         // sums over the window's collected frames
+    std::vector<std::pair<float, float>> ext_spans;   // traversal launches of the window, ms since prof_ref
+    float win_first = 0.0f, win_last = 0.0f;
     unsigned long long rays_before_frame = 0;
 };
 
@@ -90,6 +103,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags);
 int launch_trace(pt_ctx* ctx, uint32_t frame_index);
 int launch_resolve(pt_ctx* ctx);
 int sync_streams(pt_ctx* ctx);     // host waits for every chain
+int collect_slot(pt_ctx* ctx, pt_prof_slot& slot);   // waits for that frame, adds it to the timing window
 int join_chains(pt_ctx* ctx);      // main stream waits for the other chains (no host wait)
 int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
 int debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n);

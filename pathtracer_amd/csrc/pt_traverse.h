@@ -51,6 +51,7 @@ struct WaveStats {
     uint32_t node_phases = 0, node_lanes = 0;      // node phases run, lanes active in them
     uint32_t leaf_phases = 0, leaf_lanes = 0;
     uint32_t refills = 0;
+    uint32_t node_hist[4] = {0, 0, 0, 0};          // node phases with <= 8, 9..16, 17..32, 33..64 active lanes
     uint32_t longest_ray = 0;                      // loop iterations the longest-lived ray of this wave stayed in flight
     unsigned long long t_start = 0, t_exhausted = 0, t_end = 0;   // t_exhausted: the queue ran dry, only own rays left
 };
@@ -360,7 +361,9 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
     unsigned long long t_start = 0, t_exh = 0;
     uint32_t ray_steps = 0, ray_steps_max = 0;
     if (STATS && wave_stats) t_start = wall_clock64();
-    for (;;) {
+    // the cap is never reached by a well-formed hierarchy (a ray takes a few hundred steps at most); it only
+    // guarantees that every wave leaves the loop whatever the data
+    for (uint32_t iter = 0; iter < (1u << 24); iter++) {
         unsigned long long idle = __ballot(!has);
         uint32_t nidle = (uint32_t)__popcll(idle);
         if (!exhausted && nidle >= PT_REFILL_MIN) {
@@ -394,7 +397,11 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         bool at_node = has && s.cur < PT_CUR_NONE;
         if (STATS && wave_stats) {
             unsigned long long nm = __ballot(at_node);
-            if (lane == 0 && nm) { wave_stats->node_phases++; wave_stats->node_lanes += (uint32_t)__popcll(nm); }
+            if (lane == 0 && nm) {
+                uint32_t c = (uint32_t)__popcll(nm);
+                wave_stats->node_phases++; wave_stats->node_lanes += c;
+                wave_stats->node_hist[c <= 8 ? 0 : c <= 16 ? 1 : c <= 32 ? 2 : 3]++;
+            }
         }
         if (STATS && has) { ray_steps++; ray_steps_max = max(ray_steps_max, ray_steps); }
         if (at_node) {

@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, 
             atomicAdd(&stats[8], ws.t_end - ws.t_exhausted);
             atomicAdd(&stats[9], ws.t_end - ws.t_start);
             atomicMax(&stats[10], (unsigned long long)ws.longest_ray);
+            for (int k = 0; k < 4; k++) atomicAdd(&stats[11 + k], (unsigned long long)ws.node_hist[k]);
             if (wave_trace) {
                 unsigned long long* w = wave_trace + (size_t)blockIdx.x * 4;
                 w[0] = ws.t_start; w[1] = ws.t_exhausted; w[2] = ws.t_end;
@@ -484,15 +485,39 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     const bool wave_trace = counting && getenv("PT_WAVE_TRACE");
     const uint32_t chains = ctx->chains;
     const uint32_t spc = PT_SHARDS / chains;                  // shards per chain
-    size_t need_events = 2 + 2 * (size_t)rounds + 1;
+    const size_t need_events = 2 + 2 * (size_t)rounds + 1;
+    const size_t chain_words = (size_t)2 * (rounds + 1) * spc;     // queue sizes, then fetch cursors
+    pt_prof_slot* slot = nullptr;
+    bool window_start = false;
     if (prof) {
-        PT_SYNC(ctx);        // a profiled frame does not overlap its neighbours
+        if (counting) PT_SYNC(ctx);          // counted frames run one at a time
+        slot = &ctx->prof_slot[ctx->prof_next++ % PT_PROF_SLOTS];
+        {
+            int rc = collect_slot(ctx, *slot);     // its previous frame, PT_PROF_SLOTS frames ago
+            if (rc) return rc;
+        }
         for (uint32_t c = 0; c < chains; c++)
-            while (ctx->events[c].size() < need_events) {
+            while (slot->ev[c].size() < need_events) {
                 hipEvent_t e;
                 PT_HIP(ctx, hipEventCreate(&e));
-                ctx->events[c].push_back(e);
+                slot->ev[c].push_back(e);
             }
+        if (slot->h_words < chain_words * chains) {
+            if (slot->h_counts) (void)hipHostFree(slot->h_counts);
+            slot->h_counts = nullptr;
+            PT_HIP(ctx, hipHostMalloc((void**)&slot->h_counts, chain_words * chains * sizeof(uint32_t), hipHostMallocDefault));
+            slot->h_words = chain_words * chains;
+        }
+        slot->rounds = rounds;
+        slot->chains = chains;
+        if (!ctx->window_open) {
+            if (!ctx->prof_ref) PT_HIP(ctx, hipEventCreate(&ctx->prof_ref));
+            PT_HIP(ctx, hipEventRecord(ctx->prof_ref, ctx->stream));
+            ctx->timing = pt_trace_timing{};
+            ctx->ext_spans.clear();
+            ctx->window_open = true;
+            window_start = true;
+        }
     }
 
     // workgroup b of a chain's grid serves the chain's shard b % spc
@@ -502,7 +527,7 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         if (per_shard > cap_per_shard) per_shard = cap_per_shard;
         return per_shard * spc;
     };
-    static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 20u;
+    static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 28u;
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu);
     uint32_t sh_blocks = chain_grid(SHADE_BLOCK, max_blocks);
@@ -510,7 +535,7 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         int rc = ensure_spill(ctx, ext_blocks * chains);
         if (rc) return rc;
     }
-    if (counting) {
+    if (counting && window_start) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 128, ctx->stream));
         ctx->main_dirty = true;
     }
@@ -534,12 +559,11 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     }
     ctx->main_dirty = false;
 
-    const size_t chain_words = (size_t)2 * (rounds + 1) * spc;     // queue sizes, then fetch cursors
     uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
     for (uint32_t c = 0; c < chains; c++) {
         hipStream_t st = ctx->chain_stream[c];
         size_t ev = 0;
-        auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(ctx->events[c][ev++], st) : hipSuccess; };
+        auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(slot->ev[c][ev++], st) : hipSuccess; };
         uint32_t* counts = ctx->d_counts + c * chain_words;
         uint32_t* cursors = counts + (size_t)(rounds + 1) * spc;
         PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
@@ -578,13 +602,12 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
             PT_HIP(ctx, mark());
         }
         k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, ctx->d_total_rays);
+        if (prof) PT_HIP(ctx, hipMemcpyAsync(slot->h_counts + c * chain_words, counts, chain_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, mark());
     }
     PT_HIP(ctx, hipGetLastError());
     ctx->join_pending = chains > 1;
-    ctx->timing_rounds = rounds;
-    ctx->timing_chains = chains;
-    ctx->timing_pending = prof;
+    if (slot) slot->pending = true;
     return PT_OK;
 }
 

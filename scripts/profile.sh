@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_$TAG
+OUT=${PROF_OUT:-$ROOT/gpurun_out/prof_$TAG}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --steps 16 --warmup 2 --cpu-seconds 0"
