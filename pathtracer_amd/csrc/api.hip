@@ -60,7 +60,7 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
     slot.pending = false;
     pt_trace_timing& t = ctx->timing;
     const uint32_t R = slot.rounds, C = slot.chains, spc = PT_SHARDS / C;
-    const size_t chain_words = (size_t)2 * (R + 1) * spc;
+    const size_t chain_words = pt_chain_words(R, spc);
     for (uint32_t c = 0; c < C; c++) PT_HIP(ctx, hipEventSynchronize(slot.ev[c][2 + 2 * R]));
     for (uint32_t c = 0; c < C; c++) {
         std::vector<hipEvent_t>& ev = slot.ev[c];
@@ -83,6 +83,7 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
             }
             t.rays += queued;
         }
+        t.rays -= slot.h_counts[c * chain_words + (size_t)2 * (R + 1) * spc];     // deferred rays were queued twice
         float a = 0.0f, b = 0.0f;
         PT_HIP(ctx, hipEventElapsedTime(&a, ctx->prof_ref, ev[0]));
         PT_HIP(ctx, hipEventElapsedTime(&b, ctx->prof_ref, ev[2 + 2 * R]));
@@ -187,6 +188,7 @@ int pt_create(int device_ordinal, pt_ctx** out)
     uint32_t hwq = 4;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = (uint32_t)atoi(e);
     ctx->chains = hwq >= 8 ? 8u : 4u;
+    if (const char* e = getenv("PT_DEFER")) ctx->defer_rays = atoi(e) != 0;
     if (const char* e = getenv("PT_CHAINS")) {
         uint32_t c = (uint32_t)atoi(e);
         if (c >= 1 && c <= PT_MAX_CHAINS && PT_SHARDS % c == 0) ctx->chains = c;
@@ -442,11 +444,11 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
     if (!ctx->camera_set) return set_error(ctx, PT_ERR_INVALID, "pt_trace: call pt_set_camera first");
     if (frame_index == 0) return set_error(ctx, PT_ERR_INVALID, "pt_trace: frame_index is 1-based");
     PT_HIP(ctx, hipSetDevice(ctx->device));
-    uint32_t rounds = ctx->params.spp_per_frame * ctx->params.max_bounces;
+    uint32_t rounds = ctx->params.spp_per_frame * ctx->params.max_bounces + 1u;
     if (rounds + 1 > ctx->counts_cap) {
         PT_SYNC(ctx);
         (void)dev_free(ctx->d_counts);
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (size_t)2 * (rounds + 1) * PT_SHARDS * sizeof(uint32_t)));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, pt_chain_words(rounds, PT_SHARDS) * sizeof(uint32_t)));
         ctx->counts_cap = rounds + 1;
     }
     return launch_trace(ctx, frame_index);

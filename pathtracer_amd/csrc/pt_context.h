@@ -73,6 +73,7 @@ struct pt_ctx {
     uint32_t shard_cap = 0;         // ray-queue slots per shard
     uint32_t* d_counts = nullptr;   // per chain: rounds + 1 rows of queue sizes (one per shard of the chain), then as many rows of fetch cursors
     uint32_t counts_cap = 0;
+    bool defer_rays = true;         // traversal launches hand their last few rays on to the next round (PT_DEFER=0: off)
     uint2* d_spill = nullptr;       // traversal stack spill area, [chain][wave][entry][lane]
     uint32_t spill_waves = 0;
     unsigned long long* d_wave_trace = nullptr;   // PT_WAVE_TRACE=<file>: per-wave timeline of the extend launches
@@ -111,6 +112,10 @@ int debug_disney(pt_ctx* ctx, bool sample, uint32_t n, const float* surf, const 
                  const float* Lin, uint32_t* seeds, float* f, float* Lout, float* pdf);
 SceneView scene_view(const pt_ctx* ctx);
 } // namespace ptd
+
+// words of one chain's counter block: rounds + 1 rows of queue sizes, as many of fetch cursors, one row whose first
+// word counts the deferred rays
+inline size_t pt_chain_words(uint32_t rounds, uint32_t shards_per_chain) { return ((size_t)2 * (rounds + 1) + 1) * shards_per_chain; }
 
 #define PT_SYNC(ctx)                                                                              \
     do {                                                                                          \

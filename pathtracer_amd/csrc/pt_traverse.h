@@ -16,6 +16,11 @@
 // and only some lanes have one, so testing them in the owning lane would run the triangle code
 // mostly empty.  The ray travels to the testing lane, and the result back, through lane permutes.
 //
+// Tail: when the queue has run dry a wave soon walks a handful of long rays with most lanes idle, and the
+// launch lasts until the last of them is done.  Such a wave instead defers those rays (where the caller allows
+// it): they are traced again from the start by the next launch, among its first rays and in full waves.  The
+// closest hit does not depend on when or by whom a ray is traced, so results are unchanged.
+//
 // Stack: the top PT_STACK_LDS entries of each lane live in an LDS ring (one column per lane,
 // conflict free); deeper entries move in blocks to a per-wave spill area in global memory, laid
 // out [entry][lane] so that a wave's spills coalesce.  The kernel itself uses no scratch memory:
@@ -37,6 +42,9 @@ namespace ptd {
 #endif
 #ifndef PT_LEAF_MIN
 #define PT_LEAF_MIN 24     // lanes with a pending leaf that trigger the triangle phase while others still walk nodes
+#endif
+#ifndef PT_CUT_LANES
+#define PT_CUT_LANES 8     // a wave whose queue ran dry defers its rays once no more than this many are in flight
 #endif
 #define PT_CUR_NONE 0x7FFFFFFFu   // s.cur when the stack ran empty; node indices are below, leaf references above
 #define PT_OWNER_BYTES 256        // LDS bytes per wave for the triangle phase's work list
@@ -230,16 +238,26 @@ PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack
     uint32_t nzw[2] = {s.negz ? qc.z : qb.x, s.negz ? qc.w : qb.y}, fzw[2] = {s.negz ? qb.x : qc.z, s.negz ? qb.y : qc.w};
     const float bt = s.best.t, tmin = s.tmin;
     uint32_t key[8];
+    // two children per packed fma
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 vax = {ax, ax}, vay = {ay, ay}, vaz = {az, az};
+    const f2 vbnx = {bnx, bnx}, vbny = {bny, bny}, vbnz = {bnz, bnz}, vbfx = {bfx, bfx}, vbfy = {bfy, bfy}, vbfz = {bfz, bfz};
+    const f2 widen = {1.0000005f, 1.0000005f};
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 8; k += 2) {
         const int w = k >> 2, b = k & 3;
-        float tn = fmaxf(fmaxf(fmaf(ubyte_f(nxw[w], b), ax, bnx), fmaf(ubyte_f(nyw[w], b), ay, bny)),
-                         fmaxf(fmaf(ubyte_f(nzw[w], b), az, bnz), tmin));
-        float tf = fminf(fminf(fmaf(ubyte_f(fxw[w], b), ax, bfx), fmaf(ubyte_f(fyw[w], b), ay, bfy)),
-                         fmaf(ubyte_f(fzw[w], b), az, bfz)) * 1.0000005f;
-        // entered when the slab interval is non-empty and starts before the best hit (empty children decode to tn > tf)
-        bool hit = tn <= fminf(tf, bt);
-        key[k] = hit ? ((f2u(tn) & 0x7ffffff8u) | (uint32_t)k) : (PT_KEY_MISS | (uint32_t)k);
+        f2 qnx = {ubyte_f(nxw[w], b), ubyte_f(nxw[w], b + 1)}, qny = {ubyte_f(nyw[w], b), ubyte_f(nyw[w], b + 1)}, qnz = {ubyte_f(nzw[w], b), ubyte_f(nzw[w], b + 1)};
+        f2 qfx = {ubyte_f(fxw[w], b), ubyte_f(fxw[w], b + 1)}, qfy = {ubyte_f(fyw[w], b), ubyte_f(fyw[w], b + 1)}, qfz = {ubyte_f(fzw[w], b), ubyte_f(fzw[w], b + 1)};
+        f2 tnx = __builtin_elementwise_fma(qnx, vax, vbnx), tny = __builtin_elementwise_fma(qny, vay, vbny), tnz = __builtin_elementwise_fma(qnz, vaz, vbnz);
+        f2 tfx = __builtin_elementwise_fma(qfx, vax, vbfx), tfy = __builtin_elementwise_fma(qfy, vay, vbfy), tfz = __builtin_elementwise_fma(qfz, vaz, vbfz);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float tn = fmaxf(fmaxf(tnx[h], tny[h]), fmaxf(tnz[h], tmin));
+            float tf = fminf(fminf(tfx[h], tfy[h]), tfz[h]) * widen[h];
+            // entered when the slab interval is non-empty and starts before the best hit (empty children decode to tn > tf)
+            bool hit = tn <= fminf(tf, bt);
+            key[k + h] = hit ? ((f2u(tn) & 0x7ffffff8u) | (uint32_t)(k + h)) : (PT_KEY_MISS | (uint32_t)(k + h));
+        }
     }
 #define PT_CE(i, j) { uint32_t lo_ = min(key[i], key[j]); key[j] = max(key[i], key[j]); key[i] = lo_; }
     PT_CE(0, 1) PT_CE(2, 3) PT_CE(4, 5) PT_CE(6, 7)
@@ -342,13 +360,14 @@ PT_DEV void finish_hit(Trav& s)
     }
 }
 
-// Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue, emit(i, hit) stores
+// Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue and says whether the ray may be
+// deferred; emit(i, hit) stores its result; defer(i) hands ray i back untraced (see PT_CUT_LANES).
 // its result; *cursor hands out queue indices (must be 0 at launch), n = queue length.
 // lds_stack points at this lane's column: entry k is lds_stack[k * stride]; ovf points at this lane's
 // column of the wave's global spill area: entry k is ovf[k * 64]; owner is the wave's LDS work list.
-template <bool STATS, class Fetch, class Emit>
+template <bool STATS, bool CUT, class Fetch, class Emit, class Defer>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
-                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint8_t* owner, Fetch fetch, Emit emit,
+                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint8_t* owner, Fetch fetch, Emit emit, Defer defer,
                        uint32_t& stat_nodes, uint32_t& stat_tris, WaveStats* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -356,6 +375,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
     bool has = false;
     bool exhausted = false;      // wave-uniform
     uint32_t my = 0;
+    bool cuttable = false;
     s.cur = PT_CUR_NONE;
     s.pend = 0;
     unsigned long long t_start = 0, t_exh = 0;
@@ -376,7 +396,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
                 if (i < n) {
                     v3 o, d;
                     float tmin, tmax;
-                    fetch(i, o, d, tmin, tmax);
+                    cuttable = fetch(i, o, d, tmin, tmax);
                     trav_init(s, o, d, tmin, tmax);
                     my = i;
                     ray_steps = 0;
@@ -389,7 +409,13 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
                 if (STATS && wave_stats) t_exh = wall_clock64();
             }
         }
-        if (__ballot(has) == 0) {
+        unsigned long long hasm = __ballot(has);
+        if (CUT && exhausted && hasm != 0 && (uint32_t)__popcll(hasm) <= PT_CUT_LANES) {
+            // the tail of a launch: hand the last few rays back instead of walking them with a nearly empty wave
+            if (has && cuttable) { defer(my); has = false; }
+            hasm = __ballot(has);
+        }
+        if (hasm == 0) {
             if (exhausted) break;
             continue;
         }

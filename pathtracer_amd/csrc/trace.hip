@@ -133,31 +133,62 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
     }
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, float tmin, float tmax, const uint32_t* __restrict__ counts,
-                                                       uint32_t* cursors, uint32_t shard0, uint32_t nshards, uint32_t shard_cap, const float4* __restrict__ rayO,
-                                                       const float4* __restrict__ rayD, float4* __restrict__ hits, uint2* spill,
-                                                       unsigned long long* stats, unsigned long long* wave_trace)
+// hit record of a ray that was handed on to the next round untraced
+static constexpr uint32_t DEFERRED = 0xFFFFFFFEu;
+// rayD.w of a ray that must be traced to the end (its path has been deferred once already)
+#define PT_RAY_NO_DEFER 1.0f
+
+struct ExtendArgs {
+    float tmin, tmax;
+    const uint32_t* counts;     // queue sizes of this round, one per shard of the chain
+    uint32_t* cursors;          // fetch cursors of this round
+    uint32_t* next_counts;      // queue sizes of the next round (deferred rays go to its front); nullptr in launches that do not defer
+    uint32_t* deferred;         // running count of deferred rays of the chain's frame
+    uint32_t shard0, nshards, shard_cap;
+    const float4* rayO; const float4* rayD;
+    float4* next_rayO; float4* next_rayD;
+    float4* hits;
+    uint2* spill;
+};
+
+template <bool STATS, bool CUT>
+__global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, ExtendArgs a, unsigned long long* stats, unsigned long long* wave_trace)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     __shared__ uint8_t owner[PT_OWNER_BYTES];
-    const uint32_t ls = blockIdx.x % nshards;
-    const uint32_t n = counts[ls];
-    const uint32_t base = (shard0 + ls) * shard_cap;
+    const uint32_t ls = blockIdx.x % a.nshards;
+    const uint32_t n = a.counts[ls];
+    const uint32_t base = (a.shard0 + ls) * a.shard_cap;
     uint32_t sn = 0, st = 0;
     WaveStats ws;
-    trace_wave<STATS>(
-        sc.nodes, sc.tris, sc.num_tris, n, &cursors[ls], stack + threadIdx.x, EXT_BLOCK,
-        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner,
-        [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
-            float4 ro = rayO[base + i], rd = rayD[base + i];
-            o = V3(ro.x, ro.y, ro.z);
-            d = V3(rd.x, rd.y, rd.z);
-            tn = tmin;
-            tx = tmax;
-        },
-        [&](uint32_t i, const HitRec& h) { hits[base + i] = make_float4(h.t, h.u, h.v, u2f(h.tri)); }, sn, st,
-        STATS ? &ws : nullptr);
+    auto fetch = [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
+        float4 ro = a.rayO[base + i], rd = a.rayD[base + i];
+        o = V3(ro.x, ro.y, ro.z);
+        d = V3(rd.x, rd.y, rd.z);
+        tn = a.tmin;
+        tx = a.tmax;
+        return rd.w != PT_RAY_NO_DEFER;
+    };
+    auto emit = [&](uint32_t i, const HitRec& h) { a.hits[base + i] = make_float4(h.t, h.u, h.v, u2f(h.tri)); };
+    auto defer = [&](uint32_t i) {
+        // called by all lanes that defer, inside one branch: one queue slot each at the front of the next round
+        unsigned long long m = __ballot(true);
+        uint32_t lane = threadIdx.x & 63u;
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t slot0 = 0;
+        if ((int)lane == leader) {
+            slot0 = atomicAdd(&a.next_counts[ls], (uint32_t)__popcll(m));
+            atomicAdd(a.deferred, (uint32_t)__popcll(m));
+        }
+        slot0 = __shfl(slot0, leader);
+        uint32_t out = base + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        float4 ro = a.rayO[base + i], rd = a.rayD[base + i];
+        a.next_rayO[out] = ro;
+        a.next_rayD[out] = make_float4(rd.x, rd.y, rd.z, PT_RAY_NO_DEFER);
+        a.hits[base + i] = make_float4(0.0f, 0.0f, 0.0f, u2f(DEFERRED));
+    };
+    trace_wave<STATS, CUT>(sc.nodes, sc.tris, sc.num_tris, n, &a.cursors[ls], stack + threadIdx.x, EXT_BLOCK,
+                           a.spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner, fetch, emit, defer, sn, st, STATS ? &ws : nullptr);
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
@@ -337,8 +368,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
         bool alive = false;
         v3 o = V3(0.0f), d = V3(0.0f);
         uint32_t pixel = 0;
+        float no_defer = 0.0f;
+        if (valid && f2u(q.hits[slot].w) == DEFERRED) valid = false;     // the traversal kernel passed this ray on itself
         if (valid) {
             float4 ro = q.rayO_in[slot], rd = q.rayD_in[slot], h = q.hits[slot];
+            no_defer = rd.w;
             pixel = f2u(ro.w);
             o = V3(ro.x, ro.y, ro.z);
             d = V3(rd.x, rd.y, rd.z);
@@ -413,18 +447,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
         uint32_t out = shard * q.shard_cap + wave_append(alive, &q.counts[(round + 1) * q.nshards + ls]);
         if (alive) {
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
-            q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
+            q.rayD_out[out] = make_float4(d.x, d.y, d.z, no_defer);
         }
     }
 }
 
-__global__ void k_finish(const uint32_t* counts, uint32_t entries, unsigned long long* total)
+__global__ void k_finish(const uint32_t* counts, uint32_t entries, const uint32_t* deferred, unsigned long long* total)
 {
-    // one wave per chain: rays traced this frame = sum of all its queue sizes
+    // one wave per chain: rays traced this frame = sum of all its queue sizes, less the rays queued twice
     unsigned long long s = 0;
     for (uint32_t r = threadIdx.x; r < entries; r += 64) s += counts[r];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (threadIdx.x == 0) atomicAdd(total, s);
+    if (threadIdx.x == 0) atomicAdd(total, s - *deferred);
 }
 
 __global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __restrict__ image)
@@ -470,7 +504,8 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
 {
     const pt_params& pp = ctx->params;
     uint32_t npix = ctx->width * ctx->height;
-    uint32_t rounds = pp.spp_per_frame * pp.max_bounces;
+    // one round more than the longest path needs: a path whose ray was deferred runs one round late
+    const uint32_t rounds = pp.spp_per_frame * pp.max_bounces + (ctx->defer_rays ? 1u : 0u);
     TraceParams P;
     P.width = ctx->width; P.height = ctx->height;
     P.spp = pp.spp_per_frame; P.max_bounces = pp.max_bounces; P.rr_depth = pp.rr_depth;
@@ -486,7 +521,7 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     const uint32_t chains = ctx->chains;
     const uint32_t spc = PT_SHARDS / chains;                  // shards per chain
     const size_t need_events = 2 + 2 * (size_t)rounds + 1;
-    const size_t chain_words = (size_t)2 * (rounds + 1) * spc;     // queue sizes, then fetch cursors
+    const size_t chain_words = pt_chain_words(rounds, spc);        // queue sizes, fetch cursors, deferred-ray count
     pt_prof_slot* slot = nullptr;
     bool window_start = false;
     if (prof) {
@@ -566,6 +601,7 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(slot->ev[c][ev++], st) : hipSuccess; };
         uint32_t* counts = ctx->d_counts + c * chain_words;
         uint32_t* cursors = counts + (size_t)(rounds + 1) * spc;
+        uint32_t* deferred = cursors + (size_t)(rounds + 1) * spc;
         PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
         Queues q;
         q.hits = ctx->d_hits;
@@ -588,20 +624,28 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         PT_HIP(ctx, mark());
         for (uint32_t r = 0; r < rounds; r++) {
             int in = (int)(r & 1u), out = in ^ 1;
-            if (counting)
-                k_extend<true><<<ext_blocks, EXT_BLOCK, 0, st>>>(
-                    sv, P.tmin, P.tmax, counts + r * spc, cursors + r * spc, q.shard0, spc, ctx->shard_cap, ctx->d_rayO[in], ctx->d_rayD[in],
-                    ctx->d_hits, spill, ctx->d_stats, wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr);
-            else
-                k_extend<false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, P.tmin, P.tmax, counts + r * spc, cursors + r * spc, q.shard0, spc, ctx->shard_cap,
-                                                                  ctx->d_rayO[in], ctx->d_rayD[in], ctx->d_hits, spill, nullptr, nullptr);
+            ExtendArgs ea;
+            ea.tmin = P.tmin; ea.tmax = P.tmax;
+            ea.counts = counts + r * spc; ea.cursors = cursors + r * spc;
+            ea.next_counts = (ctx->defer_rays && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
+            ea.deferred = deferred;
+            ea.shard0 = q.shard0; ea.nshards = spc; ea.shard_cap = ctx->shard_cap;
+            ea.rayO = ctx->d_rayO[in]; ea.rayD = ctx->d_rayD[in];
+            ea.next_rayO = ctx->d_rayO[out]; ea.next_rayD = ctx->d_rayD[out];
+            ea.hits = ctx->d_hits;
+            ea.spill = spill;
+            unsigned long long* wt = wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr;
+            if (counting && ea.next_counts) k_extend<true, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
+            else if (counting) k_extend<true, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
+            else if (ea.next_counts) k_extend<false, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, nullptr, nullptr);
+            else k_extend<false, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, nullptr, nullptr);
             PT_HIP(ctx, mark());
             q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
             q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
             k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
             PT_HIP(ctx, mark());
         }
-        k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, ctx->d_total_rays);
+        k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, deferred, ctx->d_total_rays);
         if (prof) PT_HIP(ctx, hipMemcpyAsync(slot->h_counts + c * chain_words, counts, chain_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, mark());
     }
@@ -629,7 +673,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     __shared__ uint8_t owner[PT_OWNER_BYTES];
     uint32_t sn = 0, st = 0;
-    trace_wave<true>(
+    trace_wave<true, false>(
         sc.nodes, sc.tris, sc.num_tris, n, cursor, stack + threadIdx.x, EXT_BLOCK,
         spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
@@ -638,12 +682,14 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
             d = V3(rd.x, rd.y, rd.z);
             tn = ro.w;
             tx = rd.w;
+            return false;
         },
         [&](uint32_t i, const HitRec& h) {
             uint32_t* o = out + (size_t)i * 5;
             if (h.tri == MISS) { o[0] = f2u(h.t); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }   // h.t is still tmax
             else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = sc.tris[h.tri].submesh; o[4] = sc.tris[h.tri].prim; }
-        }, sn, st);
+        },
+        [&](uint32_t) {}, sn, st);
     atomicAdd(&stats[0], (unsigned long long)sn);
     atomicAdd(&stats[1], (unsigned long long)st);
 }

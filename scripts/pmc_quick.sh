@@ -14,7 +14,7 @@ python3 - <<PY
 import sqlite3, glob
 for path in sorted(glob.glob("$OUT/*/pmc_results.db")):
     d = sqlite3.connect(path)
-    rows = d.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%k_extend<false>%' or kernel_name like '%k_shade%' group by kernel_name, counter_name").fetchall()
+    rows = d.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%k_extend<false,%' or kernel_name like '%k_shade%' group by kernel_name, counter_name").fetchall()
     for k, c, n, a in rows:
         print(("extend" if "extend" in k else "shade"), c, n, "%.5g" % a)
 PY

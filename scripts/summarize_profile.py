@@ -18,7 +18,7 @@ os.makedirs(out_dir, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"(ptd::k_\w+(<\w+>)?|__amd_rocclr_\w+|rocprim\S*?::(\w+_kernel|trampoline_kernel))", name)
+    m = re.search(r"(ptd::k_\w+(<[\w, ]+>)?|__amd_rocclr_\w+|rocprim\S*?::(\w+_kernel|trampoline_kernel))", name)
     return m.group(1) if m else name[:60]
 
 
@@ -50,7 +50,9 @@ for path in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_results.db"))):
         if "ptd::" not in kname:
             continue
         pmc.setdefault(short(kname), {})[cname] = {"dispatches": n, "avg": avg, "sum": total}
-ext = pmc.get("ptd::k_extend<false>", {})
+# the production traversal kernel: k_extend<false, true> (rounds that may defer rays); the last round of a frame
+# runs k_extend<false, false> on a nearly empty queue
+ext = pmc.get("ptd::k_extend<false, true>", {})
 summary = {"source": "rocprofv3 --pmc, one pass per counter group, bench.py --steps 16 --warmup 2 --cpu-seconds 0", "per_kernel": pmc}
 if "FETCH_SIZE" in ext:
     raw_kb = ext["FETCH_SIZE"]["avg"]
