@@ -135,6 +135,21 @@ int pt_write_accum(pt_ctx* ctx, const float* rgba);
 /* o_Image = accum.rgb / accum.a for every pixel (RayGen.glsl:367-372), for an accumulation
  * image that was merged from several GPUs. */
 int pt_resolve(pt_ctx* ctx);
+/* PostProcessingPass (RayTracingLayer.cpp:286-318, PostProcessing.glsl:14-55): exposure (the reference's
+ * default is 0.8, RayTracingLayer.h:92), ACES fit, gamma 2.2, stored as RGBA8 into an image the context owns
+ * (m_PostProcessingImage).  Runs on the main stream after the frames issued so far. */
+int pt_postprocess(pt_ctx* ctx, float exposure);
+int pt_read_postprocessed(pt_ctx* ctx, uint8_t* rgba8);      /* width*height*4 bytes */
+void* pt_device_postprocessed(pt_ctx* ctx);
+/* Environment sources for binding 10.  Both replace the cube map set by pt_scene_upload (call them after it).
+ * pt_env_from_equirect: what the engine's TextureCube does with its .hdr radiance image (RayTracingLayer.cpp:50-54,
+ *   EquirectangularToCubeMap.glsl:11-40): rgba = width*height*4 floats, row 0 = top; the cube holds binary16 values.
+ * pt_env_preetham: the Preetham sky pass (RayTracingLayer.cpp:56-76,366-381, PreethamSky.glsl:17-146; defaults
+ *   turbidity 3.14, azimuth 0, inclination 0 at RayTracingLayer.h:88, 2048 texels per face).
+ * pt_read_env: the current cube, 6*n*n*4 floats, faces +X -X +Y -Y +Z -Z; rgba may be NULL to query n only. */
+int pt_env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t width, uint32_t height, uint32_t face_size);
+int pt_env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclination, uint32_t face_size);
+int pt_read_env(pt_ctx* ctx, float* rgba, uint32_t* face_size);
 /* (gl_InstanceCustomIndexEXT, gl_PrimitiveID) of the first sample's primary ray of the last
  * frame, per pixel; 0xFFFFFFFF twice for a miss.  width*height*2 words. */
 int pt_read_primary_ids(pt_ctx* ctx, uint32_t* submesh_prim_pairs);
@@ -166,7 +181,8 @@ void* pt_device_accum(pt_ctx* ctx);
  * hits = n*5 words: t,u,v (float bits), submesh, prim; miss = (tmax,0,0,~0,~0).
  * counters (may be NULL) = 2 uint64: hierarchy nodes visited, triangles tested. */
 int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
-/* the deterministic sin/cos/log/exp/pow used by the kernels: fn 0 sin,1 cos,2 log,3 exp,4 pow */
+/* the deterministic functions used by the kernels: fn 0 sin, 1 cos, 2 log, 3 exp, 4 pow(x,y), 5 atan2(x,y),
+ * 6 acos, 7 tan, 8 binary32 -> binary16 -> binary32 rounding */
 int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n);
 /* DisneySample / DisneyEval (Disney.glsl:150-359) for n independent inputs.
  * surf = n*17 floats: albedo3 metallic roughness subsurface specularTint sheen sheenTint

@@ -57,6 +57,17 @@ int pth_layer_read_image(pth_layer* l, float* rgba);
 int pth_layer_read_accum(pth_layer* l, float* rgba);
 int pth_layer_ray_count(pth_layer* l, uint64_t* rays);
 const char* pth_layer_last_error(pth_layer* l);
+/* TextureCube{path = "...hdr"} (RayTracingLayer.cpp:50-54): load a Radiance image and make it the environment */
+int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face_size);
+/* m_DoPostProcessing / m_Exposure (RayTracingLayer.h:90-92, RayTracingLayer.cpp:522-524); on by default, 0.8 */
+int pth_layer_set_post_processing(pth_layer* l, int on, float exposure);
+int pth_layer_read_postprocessed(pth_layer* l, uint8_t* rgba8);   /* m_PostProcessingImage after the last on_render */
+
+/* Radiance .hdr (RGBE) reader: *rgba = malloc'ed width*height*4 floats (row 0 = top, alpha 1), free with pth_pixels_free */
+int pth_hdr_load(const char* path, uint32_t* width, uint32_t* height, float** rgba, char* err, size_t errlen);
+void pth_pixels_free(float* rgba);
+/* binary PPM (P6) of an RGBA8 image, alpha dropped */
+int pth_ppm_write(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, char* err, size_t errlen);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,12 @@
 //   exp    : k = rne(x / ln2); r = x - k*ln2 (two-part, fma); degree-6 polynomial;
 //            scaling by 2^k in two exact steps.
 //   pow    : exp(y * log(x))   (GLSL: pow(x,y) undefined for x < 0).
+//   atan   : |x| > tan(3pi/8): pi/2 - atan(1/|x|); |x| > tan(pi/8): pi/4 + atan((|x|-1)/(|x|+1));
+//            odd degree-9 polynomial on the rest (the single-precision Cephes recipe).
+//   atan2  : atan(|y/x|), reflected to pi - t for x < 0, negated for y < 0; atan2(0, 0) = 0.
+//   acos   : atan2(sqrt((1-x)(1+x)), x) with x clamped to [-1, 1]  (GLSL: undefined outside).
+//   tan    : sin / cos.
+//   half   : binary32 -> binary16 -> binary32 with round-to-nearest-even, by integer arithmetic.
 //
 // Accuracy (checked in tests/test_oracle_kat.py against float64 libm): <= 2 ulp for
 // sin/cos on [0, 2*pi], log on (0, 1e30), exp on [-87, 88].
@@ -131,5 +137,58 @@ static inline float det_exp(float x)
 }
 
 static inline float det_pow(float x, float y) { return det_exp(y * det_log(x)); }
+
+static inline float det_atan(float xx)
+{
+    const float PIO2 = 1.5707963267948966f, PIO4 = 0.7853981633974483f;
+    if (xx != xx) return xx;
+    float x = u2f(f2u(xx) & 0x7fffffffu);
+    float y = 0.0f;
+    if (x > 2.414213562373095f) { y = PIO2; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = PIO4; x = (x - 1.0f) / (x + 1.0f); }
+    float z = x * x;
+    float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+    p = fmaf(z, p, 1.99777106478e-1f);
+    p = fmaf(z, p, -3.33329491539e-1f);
+    y = y + fmaf(p * z, x, x);
+    return (f2u(xx) >> 31) ? -y : y;
+}
+
+static inline float det_atan2(float y, float x)
+{
+    const float PI_F = 3.14159265358979323846f;
+    if (y != y || x != x) return u2f(0x7fc00000u);
+    float ay = u2f(f2u(y) & 0x7fffffffu), ax = u2f(f2u(x) & 0x7fffffffu);
+    if (ay == 0.0f && ax == 0.0f) return 0.0f;
+    float t = (ay == __builtin_inff() && ax == __builtin_inff()) ? 0.7853981633974483f : det_atan(ay / ax);   // inf/inf would be a NaN whose sign differs between machines
+    if (f2u(x) >> 31) t = PI_F - t;
+    return (f2u(y) >> 31) ? -t : t;
+}
+
+static inline float det_acos(float x)
+{
+    if (x != x) return x;
+    x = gclamp(x, -1.0f, 1.0f);
+    return det_atan2(std::sqrt((1.0f - x) * (1.0f + x)), x);
+}
+
+static inline float det_tan(float x) { float s, c; det_sincos(x, &s, &c); return s / c; }
+
+// value of x after a round trip through IEEE binary16 (round to nearest even; overflow to infinity)
+static inline float round_to_half(float f)
+{
+    uint32_t u = f2u(f), sign = u & 0x80000000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return f;                                // inf, NaN
+    if (a >= 0x477ff000u) return u2f(sign | 0x7f800000u);          // >= 65520 rounds to infinity
+    if (a < 0x33000001u) return u2f(sign);                          // <= 2^-25 rounds to zero
+    if (a < 0x38800000u) {                                          // subnormal half: multiples of 2^-24
+        float scaled = u2f(a) * 16777216.0f;                        // exact
+        float r = (scaled + 12582912.0f) - 12582912.0f;             // rne to integer
+        return u2f(f2u(r * 5.9604644775390625e-8f) | sign);
+    }
+    uint32_t rem = a & 0x1fffu, base = a & ~0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (base & 0x2000u))) base += 0x2000u;
+    return u2f(sign | base);
+}
 
 } // namespace orc

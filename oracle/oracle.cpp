@@ -8,6 +8,7 @@
 #include "oracle.h"
 #include "intersect.h"
 #include "shaders.h"
+#include "passes.h"
 #include <atomic>
 #include <thread>
 
@@ -462,9 +463,32 @@ void orc_det_math(int fn, const float* x, const float* y, float* out, uint32_t n
         case 1: out[i] = det_cos(x[i]); break;
         case 2: out[i] = det_log(x[i]); break;
         case 3: out[i] = det_exp(x[i]); break;
-        default: out[i] = det_pow(x[i], y[i]); break;
+        case 4: out[i] = det_pow(x[i], y[i]); break;
+        case 5: out[i] = det_atan2(x[i], y[i]); break;
+        case 6: out[i] = det_acos(x[i]); break;
+        case 7: out[i] = det_tan(x[i]); break;
+        default: out[i] = round_to_half(x[i]); break;
         }
     }
+}
+
+void orc_postprocess(const float* rgba, uint32_t num_pixels, float exposure, uint8_t* rgba8)
+{
+    for (uint32_t i = 0; i < num_pixels; i++) PostProcessPixel(rgba + (size_t)i * 4, exposure, rgba8 + (size_t)i * 4);
+}
+
+void orc_equirect_to_cube(const float* rgba, uint32_t w, uint32_t h, uint32_t n, float* cube)
+{
+    for (uint32_t f = 0; f < 6; f++)
+        for (uint32_t y = 0; y < n; y++)
+            for (uint32_t x = 0; x < n; x++) EquirectToCubeTexel(rgba, w, h, x, y, f, n, cube + (((size_t)f * n + y) * n + x) * 4);
+}
+
+void orc_preetham_sky(float turbidity, float azimuth, float inclination, uint32_t n, float* cube)
+{
+    for (uint32_t f = 0; f < 6; f++)
+        for (uint32_t y = 0; y < n; y++)
+            for (uint32_t x = 0; x < n; x++) PreethamTexel(turbidity, azimuth, inclination, x, y, f, n, cube + (((size_t)f * n + y) * n + x) * 4);
 }
 
 void orc_disney_sample(const float* surf, const float* V, const float* N, uint32_t* seed, float* f, float* L, float* pdf)

@@ -68,7 +68,11 @@ int orc_intersect(orc_ctx*, const float* rays, uint32_t n, uint32_t* hits, int u
 uint32_t orc_pcg_hash(uint32_t* seed);
 float orc_random_value(uint32_t* seed);
 /* fn: 0 sin, 1 cos, 2 log, 3 exp, 4 pow(x, y) */
-void orc_det_math(int fn, const float* x, const float* y, float* out, uint32_t n);
+void orc_det_math(int fn, const float* x, const float* y, float* out, uint32_t n);   /* fn: 0 sin 1 cos 2 log 3 exp 4 pow 5 atan2 6 acos 7 tan 8 round-to-half */
+/* PostProcessing.glsl, EquirectangularToCubeMap.glsl, PreethamSky.glsl (oracle/passes.h) */
+void orc_postprocess(const float* rgba, uint32_t num_pixels, float exposure, uint8_t* rgba8);
+void orc_equirect_to_cube(const float* rgba, uint32_t w, uint32_t h, uint32_t face_size, float* cube);
+void orc_preetham_sky(float turbidity, float azimuth, float inclination, uint32_t face_size, float* cube);
 /* surf = 17 floats: albedo3 metallic roughness subsurface specularTint sheen sheenTint
  * clearcoat clearcoatRoughness specTrans ior ax ay eta anisotropic(unused by BSDF);
  * V, N world vectors; returns f (3), L (3), pdf and the advanced seed. */

@@ -17,6 +17,7 @@ EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_default_params", "pt_scene_upload", "pt_build_accel",
     "pt_update_materials", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
+    "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
     "pt_set_chains", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_device_image", "pt_device_accum",
     "pt_debug_intersect", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
 ]
@@ -75,10 +76,15 @@ def load_library():
     lib.pt_resolve.argtypes = [vp]
     lib.pt_read_primary_ids.argtypes = [vp, up]
     lib.pt_ray_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.pt_postprocess.argtypes = [vp, C.c_float]
+    lib.pt_read_postprocessed.argtypes = [vp, C.POINTER(C.c_uint8)]
+    lib.pt_env_from_equirect.argtypes = [vp, fp, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.pt_env_preetham.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_uint32]
+    lib.pt_read_env.argtypes = [vp, fp, up]
     lib.pt_set_chains.argtypes = [vp, C.c_uint32]
     lib.pt_set_profiling.argtypes = [vp, C.c_int]
     lib.pt_last_trace_timing.argtypes = [vp, C.POINTER(TraceTiming)]
-    for name in ("pt_stream", "pt_device_image", "pt_device_accum"):
+    for name in ("pt_stream", "pt_device_image", "pt_device_accum", "pt_device_postprocessed"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
     lib.pt_debug_intersect.argtypes = [vp, fp, C.c_uint32, up, C.POINTER(C.c_uint64)]
@@ -192,6 +198,29 @@ class Backend:
         v = C.c_uint64()
         self._check(self.lib.pt_ray_count(self.h, C.byref(v)))
         return v.value
+
+    def postprocess(self, exposure=0.8):
+        """Exposure, ACES fit, gamma 2.2 -> RGBA8 (H, W, 4) uint8 of the current image."""
+        self._check(self.lib.pt_postprocess(self.h, float(exposure)))
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._check(self.lib.pt_read_postprocessed(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def env_from_equirect(self, rgba, face_size):
+        """rgba: (H, W, 4) float32 lat-long radiance image, row 0 = top."""
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        h, w = rgba.shape[:2]
+        self._check(self.lib.pt_env_from_equirect(self.h, _fp(rgba), w, h, int(face_size)))
+
+    def env_preetham(self, turbidity=3.14, azimuth=0.0, inclination=0.0, face_size=2048):
+        self._check(self.lib.pt_env_preetham(self.h, float(turbidity), float(azimuth), float(inclination), int(face_size)))
+
+    def read_env(self):
+        n = C.c_uint32(0)
+        self._check(self.lib.pt_read_env(self.h, None, C.byref(n)))
+        out = np.empty((6, n.value, n.value, 4), np.float32)
+        self._check(self.lib.pt_read_env(self.h, _fp(out), C.byref(n)))
+        return out
 
     def set_chains(self, chains):
         """Number of independent pipelines (1, 2, 4 or 8) a frame is split into; images do not depend on it."""

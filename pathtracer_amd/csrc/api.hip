@@ -39,7 +39,7 @@ static void free_scene(pt_ctx* c)
 
 static void free_images(pt_ctx* c)
 {
-    (void)dev_free(c->d_image_own); (void)dev_free(c->d_accum_own); (void)dev_free(c->d_primary);
+    (void)dev_free(c->d_image_own); (void)dev_free(c->d_accum_own); (void)dev_free(c->d_primary); (void)dev_free(c->d_post);
     (void)dev_free(c->d_rayO[0]); (void)dev_free(c->d_rayO[1]); (void)dev_free(c->d_rayD[0]); (void)dev_free(c->d_rayD[1]);
     (void)dev_free(c->d_hits); (void)dev_free(c->d_stA); (void)dev_free(c->d_stB); (void)dev_free(c->d_stC);
     c->d_image = c->d_accum = nullptr;
@@ -493,6 +493,61 @@ int pt_resolve(pt_ctx* ctx)
     return launch_resolve(ctx);
 }
 
+int pt_postprocess(pt_ctx* ctx, float exposure)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "no image: call pt_resize first");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_postprocess(ctx, exposure);
+}
+
+int pt_read_postprocessed(pt_ctx* ctx, uint8_t* rgba8)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->d_post) return set_error(ctx, PT_ERR_INVALID, "pt_read_postprocessed: call pt_postprocess first");
+    return read_back(ctx, rgba8, ctx->d_post, (size_t)ctx->width * ctx->height * 4);
+}
+
+void* pt_device_postprocessed(pt_ctx* ctx) { return ctx ? (void*)ctx->d_post : nullptr; }
+
+static int check_env_args(pt_ctx* ctx, uint32_t face_size)
+{
+    if (!ctx->scene_loaded) return set_error(ctx, PT_ERR_INVALID, "environment: upload the scene first (pt_scene_upload resets the environment)");
+    if (face_size == 0 || face_size > 8192) return set_error(ctx, PT_ERR_INVALID, "environment: face size must be 1..8192");
+    return PT_OK;
+}
+
+int pt_env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t width, uint32_t height, uint32_t face_size)
+{
+    if (!ctx || !rgba) return PT_ERR_INVALID;
+    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28)) return set_error(ctx, PT_ERR_INVALID, "pt_env_from_equirect: bad image size");
+    int rc = check_env_args(ctx, face_size);
+    if (rc) return rc;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return env_from_equirect(ctx, rgba, width, height, face_size);
+}
+
+int pt_env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclination, uint32_t face_size)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    int rc = check_env_args(ctx, face_size);
+    if (rc) return rc;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return env_preetham(ctx, turbidity, azimuth, inclination, face_size);
+}
+
+int pt_read_env(pt_ctx* ctx, float* rgba, uint32_t* face_size)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->d_env) return set_error(ctx, PT_ERR_INVALID, "pt_read_env: no environment (upload a scene first)");
+    if (face_size) *face_size = ctx->env_n;
+    if (!rgba) return PT_OK;
+    PT_SYNC(ctx);
+    PT_HIP(ctx, hipMemcpyAsync(rgba, ctx->d_env, (size_t)6 * ctx->env_n * ctx->env_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    PT_SYNC(ctx);
+    return PT_OK;
+}
+
 int pt_ray_count(pt_ctx* ctx, uint64_t* rays)
 {
     if (!ctx || !rays) return PT_ERR_INVALID;
@@ -536,7 +591,7 @@ int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hit
 int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n)
 {
     if (!ctx || (n && (!x || !out))) return PT_ERR_INVALID;
-    if (fn < 0 || fn > 4 || (fn == 4 && !y)) return set_error(ctx, PT_ERR_INVALID, "pt_debug_math: bad function id");
+    if (fn < 0 || fn > 8 || ((fn == 4 || fn == 5) && !y)) return set_error(ctx, PT_ERR_INVALID, "pt_debug_math: bad function id");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     return debug_math(ctx, fn, x, y, out, n);
 }

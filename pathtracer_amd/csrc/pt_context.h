@@ -62,6 +62,7 @@ struct pt_ctx {
     float* d_image = nullptr;     // own or bound
     float* d_accum = nullptr;
     uint2* d_primary = nullptr;
+    uint32_t* d_post = nullptr;   // post-processed RGBA8 image, allocated by the first pt_postprocess
 
     // wavefront state
     float4* d_rayO[2] = {nullptr, nullptr};
@@ -103,6 +104,9 @@ int set_error(pt_ctx* ctx, int code, const std::string& msg);
 int build_accel(pt_ctx* ctx, uint32_t flags);
 int launch_trace(pt_ctx* ctx, uint32_t frame_index);
 int launch_resolve(pt_ctx* ctx);
+int launch_postprocess(pt_ctx* ctx, float exposure);
+int env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t w, uint32_t h, uint32_t face_size);
+int env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclination, uint32_t face_size);
 int sync_streams(pt_ctx* ctx);     // host waits for every chain
 int collect_slot(pt_ctx* ctx, pt_prof_slot& slot);   // waits for that frame, adds it to the timing window
 int join_chains(pt_ctx* ctx);      // main stream waits for the other chains (no host wait)

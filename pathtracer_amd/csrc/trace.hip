@@ -704,7 +704,11 @@ __global__ void k_debug_math(int fn, uint32_t n, const float* __restrict__ x, co
     case 1: det_sincos(x[i], s, c); out[i] = c; break;
     case 2: out[i] = det_log(x[i]); break;
     case 3: out[i] = det_exp(x[i]); break;
-    default: out[i] = det_pow(x[i], y[i]); break;
+    case 4: out[i] = det_pow(x[i], y[i]); break;
+    case 5: out[i] = det_atan2(x[i], y[i]); break;
+    case 6: out[i] = det_acos(x[i]); break;
+    case 7: out[i] = det_tan(x[i]); break;
+    default: out[i] = round_to_half(x[i]); break;
     }
 }
 

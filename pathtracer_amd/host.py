@@ -17,6 +17,8 @@ EXPORTS = [
     "pth_layer_set_viewport", "pth_layer_set_params", "pth_layer_set_accumulate", "pth_layer_set_camera_position",
     "pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render", "pth_layer_frame_index",
     "pth_layer_read_image", "pth_layer_read_accum", "pth_layer_ray_count", "pth_layer_last_error",
+    "pth_layer_set_radiance_map", "pth_layer_set_post_processing", "pth_layer_read_postprocessed",
+    "pth_hdr_load", "pth_pixels_free", "pth_ppm_write",
 ]
 
 
@@ -67,6 +69,13 @@ def load_library():
     L.pth_layer_read_accum.argtypes = [vp, fp]
     L.pth_layer_ray_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.pth_layer_last_error.argtypes = [vp]
+    L.pth_layer_set_radiance_map.argtypes = [vp, C.c_char_p, C.c_uint32]
+    L.pth_layer_set_post_processing.argtypes = [vp, C.c_int, C.c_float]
+    L.pth_layer_read_postprocessed.argtypes = [vp, C.POINTER(C.c_uint8)]
+    L.pth_hdr_load.argtypes = [C.c_char_p, up, up, C.POINTER(fp), C.c_char_p, C.c_size_t]
+    L.pth_pixels_free.argtypes = [fp]
+    L.pth_pixels_free.restype = None
+    L.pth_ppm_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_char_p, C.c_size_t]
     L.pth_layer_last_error.restype = C.c_char_p
     _lib = L
     return L
@@ -212,3 +221,35 @@ class RayTracingLayer:
         v = C.c_uint64()
         self._check(self.L.pth_layer_ray_count(self.h, C.byref(v)))
         return v.value
+
+    def SetRadianceMap(self, hdr_path, face_size=1024):
+        self._check(self.L.pth_layer_set_radiance_map(self.h, os.fsencode(hdr_path), face_size))
+
+    def SetPostProcessing(self, on=True, exposure=0.8):
+        self._check(self.L.pth_layer_set_post_processing(self.h, int(on), exposure))
+
+    def ReadPostProcessed(self):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._check(self.L.pth_layer_read_postprocessed(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+
+def load_hdr(path):
+    """Radiance .hdr -> (H, W, 4) float32, row 0 = top, alpha 1 (C++ reader of the host layer)."""
+    L = load_library()
+    w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_float)()
+    err = C.create_string_buffer(512)
+    if L.pth_hdr_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px), err, len(err)):
+        raise RuntimeError(err.value.decode())
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, 4)).copy()
+    finally:
+        L.pth_pixels_free(px)
+
+
+def write_ppm(path, rgba8):
+    L = load_library()
+    a = np.ascontiguousarray(rgba8, np.uint8)
+    err = C.create_string_buffer(512)
+    if L.pth_ppm_write(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.POINTER(C.c_uint8)), err, len(err)):
+        raise RuntimeError(err.value.decode())

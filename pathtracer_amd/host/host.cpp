@@ -318,6 +318,26 @@ void RayTracingLayer::OnRender()
     m_CameraBuffer.InverseProjection = m_Camera->GetInverseProjection();
     m_Device->Check(pt_set_camera(m_Device->Get(), reinterpret_cast<const float*>(&m_CameraBuffer)), "pt_set_camera");
     RayTracingPass();
+    PostProcessingPass();                 // RayTracingLayer.cpp:421
+}
+
+void RayTracingLayer::PostProcessingPass()
+{
+    if (m_DoPostProcessing) m_Device->Check(pt_postprocess(m_Device->Get(), m_Exposure), "pt_postprocess");
+}
+
+std::vector<uint8_t> RayTracingLayer::ReadPostProcessed()
+{
+    std::vector<uint8_t> out((size_t)m_ViewportWidth * m_ViewportHeight * 4);
+    m_Device->Check(pt_read_postprocessed(m_Device->Get(), out.data()), "pt_read_postprocessed");
+    return out;
+}
+
+void RayTracingLayer::SetRadianceMap(const std::string& hdrPath, uint32_t faceSize)
+{
+    HdrImage img = LoadHdr(hdrPath);
+    m_Device->Check(pt_env_from_equirect(m_Device->Get(), img.Pixels.data(), img.Width, img.Height, faceSize), "pt_env_from_equirect");
+    m_SceneBuffer.FrameIndex = 1;         // a new sky restarts the accumulation (RayTracingLayer.cpp:356-357)
 }
 
 void RayTracingLayer::RayTracingPass()

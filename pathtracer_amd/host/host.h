@@ -223,6 +223,14 @@ struct SceneBuffer {                                   // RayTracingLayer.h:26-3
     float AbsorptionFactor[3] = {1, 1, 1};
 };
 
+// image_io.cpp
+struct HdrImage {
+    uint32_t Width = 0, Height = 0;
+    std::vector<float> Pixels;     // RGBA32F, row 0 = top, alpha 1
+};
+HdrImage LoadHdr(const std::string& path);                                               // Radiance RGBE, flat or run-length encoded
+void WritePpm(const std::string& path, uint32_t width, uint32_t height, const uint8_t* rgba8);
+
 // Headless counterpart of the reference's RayTracingLayer: same members, same frame sequencing.
 class RayTracingLayer {
 public:
@@ -233,6 +241,9 @@ public:
     void SetAccumulate(bool on) { m_Accumulate = on; }
     void SetParams(const pt_params& p);
     void MaterialsChanged();                                   // RayTracingLayer.cpp:618-622
+    void SetRadianceMap(const std::string& hdrPath, uint32_t faceSize = 1024);   // RayTracingLayer.cpp:50-54 (TextureCube of the engine)
+    void SetPostProcessing(bool on, float exposure) { m_DoPostProcessing = on; m_Exposure = exposure; }   // RayTracingLayer.cpp:522-524
+    std::vector<uint8_t> ReadPostProcessed();                  // m_PostProcessingImage, RGBA8
     Ref<Camera> GetCamera() const { return m_Camera; }
     Ref<Image> GetImage() const { return m_Image; }
     Ref<Image> GetAccumulationImage() const { return m_AccumulationImage; }
@@ -242,6 +253,7 @@ public:
 
 private:
     void RayTracingPass();                                     // RayTracingLayer.cpp:201-284
+    void PostProcessingPass();                                 // RayTracingLayer.cpp:286-318
     void CreateAccelerationStructure();                        // RayTracingLayer.cpp:342-348
     Ref<Device> m_Device;
     Ref<Mesh> m_Mesh;
@@ -254,6 +266,8 @@ private:
     SceneBuffer m_SceneBuffer;
     uint32_t m_ViewportWidth = 1, m_ViewportHeight = 1;
     bool m_Resized = true;
+    bool m_DoPostProcessing = true;                            // RayTracingLayer.h:90
+    float m_Exposure = 0.8f;                                   // RayTracingLayer.h:92
 };
 
 } // namespace ptamd

@@ -2,7 +2,10 @@
 #include "../../include/pathtracer_host.h"
 #include "host.h"
 #include <cstdio>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 
 using namespace ptamd;
 
@@ -171,5 +174,41 @@ int pth_layer_read_accum(pth_layer* l, float* rgba)
 }
 int pth_layer_ray_count(pth_layer* l, uint64_t* rays) { return guarded(l, [&] { *rays = l->layer->GetRayCount(); }); }
 const char* pth_layer_last_error(pth_layer* l) { return l ? l->error.c_str() : ""; }
+
+int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face_size)
+{
+    return guarded(l, [&] { l->layer->SetRadianceMap(hdr_path, face_size); });
+}
+int pth_layer_set_post_processing(pth_layer* l, int on, float exposure) { return guarded(l, [&] { l->layer->SetPostProcessing(on != 0, exposure); }); }
+int pth_layer_read_postprocessed(pth_layer* l, uint8_t* rgba8)
+{
+    return guarded(l, [&] { std::vector<uint8_t> px = l->layer->ReadPostProcessed(); std::memcpy(rgba8, px.data(), px.size()); });
+}
+
+int pth_hdr_load(const char* path, uint32_t* width, uint32_t* height, float** rgba, char* err, size_t errlen)
+{
+    try {
+        ptamd::HdrImage img = ptamd::LoadHdr(path);
+        float* px = (float*)malloc(img.Pixels.size() * sizeof(float));
+        if (!px) throw std::runtime_error("out of memory");
+        std::memcpy(px, img.Pixels.data(), img.Pixels.size() * sizeof(float));
+        *width = img.Width; *height = img.Height; *rgba = px;
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return 1;
+    }
+}
+void pth_pixels_free(float* rgba) { free(rgba); }
+int pth_ppm_write(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, char* err, size_t errlen)
+{
+    try {
+        ptamd::WritePpm(path, width, height, rgba8);
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return 1;
+    }
+}
 
 } // extern "C"

@@ -64,6 +64,12 @@ def lib():
     L.orc_random_value.restype = C.c_float
     L.orc_det_math.argtypes = [C.c_int, fp, fp, fp, C.c_uint32]
     L.orc_det_math.restype = None
+    L.orc_postprocess.argtypes = [fp, C.c_uint32, C.c_float, C.POINTER(C.c_uint8)]
+    L.orc_postprocess.restype = None
+    L.orc_equirect_to_cube.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, fp]
+    L.orc_equirect_to_cube.restype = None
+    L.orc_preetham_sky.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32, fp]
+    L.orc_preetham_sky.restype = None
     L.orc_disney_sample.argtypes = [fp, fp, fp, up, fp, fp, fp]
     L.orc_disney_sample.restype = None
     L.orc_disney_eval.argtypes = [fp, fp, fp, fp, fp, fp]
@@ -175,6 +181,27 @@ def det_math(fn, x, y=None):
     y = np.zeros_like(x) if y is None else np.ascontiguousarray(y, np.float32).reshape(-1)
     out = np.empty_like(x)
     lib().orc_det_math(fn, _fp(x), _fp(y), _fp(out), len(x))
+    return out
+
+
+def postprocess(rgba, exposure=0.8):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    out = np.empty(rgba.shape[:-1] + (4,), np.uint8)
+    lib().orc_postprocess(_fp(rgba), rgba.size // 4, exposure, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def equirect_to_cube(rgba, face_size):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[:2]
+    out = np.empty((6, face_size, face_size, 4), np.float32)
+    lib().orc_equirect_to_cube(_fp(rgba), w, h, face_size, _fp(out))
+    return out
+
+
+def preetham_sky(turbidity, azimuth, inclination, face_size):
+    out = np.empty((6, face_size, face_size, 4), np.float32)
+    lib().orc_preetham_sky(turbidity, azimuth, inclination, face_size, _fp(out))
     return out
 
 

@@ -450,3 +450,82 @@ def test_error_reporting(backend, cornell):
         backend.set_params(Params.reference(spp_per_frame=0))
     with pytest.raises(BackendError):
         backend.resize(0, 4)
+
+
+# ---- compute passes around the path tracer ---------------------------------------------------------------------
+@pytest.mark.parametrize("fn", [5, 6, 7, 8])
+def test_det_math_of_the_passes_bit_exact(backend, fn):
+    rng = np.random.default_rng(40 + fn)
+    n = 300000
+    x = (rng.normal(size=n) * np.exp(rng.uniform(-25, 15, n))).astype(np.float32)
+    y = (rng.normal(size=n) * np.exp(rng.uniform(-25, 15, n))).astype(np.float32)
+    if fn == 6:
+        x = rng.uniform(-1.001, 1.001, n).astype(np.float32)
+    if fn == 7:
+        x = rng.uniform(-100, 100, n).astype(np.float32)
+    x[:10] = [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 65520.0, 2.0 ** -25, 1e-45]
+    y[:10] = [0.0, -0.0, 0.0, -0.0, np.inf, 1.0, 1.0, np.nan, -np.inf, -1e-45]
+    got = backend.debug_math(fn, x, y if fn == 5 else None)
+    want = oracle_lib.det_math(fn, x, y)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_postprocess_bit_exact(backend, cornell, cameras):
+    o, rays = render_pair(backend, cornell, cameras["512x512"], 200, 120, (1, 2, 3), spp_per_frame=2, max_bounces=4)
+    for exposure in (0.8, 0.0, 7.5):
+        got = backend.postprocess(exposure)
+        want = oracle_lib.postprocess(o.read_image(), exposure)
+        assert got.shape == (120, 200, 4) and np.array_equal(got, want)
+    # arbitrary radiance, including what a renderer can produce by accident
+    rng = np.random.default_rng(3)
+    img = np.exp(rng.uniform(-12, 8, (120, 200, 4))).astype(np.float32)
+    img[0, :6, 0] = [np.nan, np.inf, -np.inf, -1.0, 0.0, 1e30]
+    backend.write_accum(np.concatenate([img[..., :3], np.ones((120, 200, 1), np.float32)], -1))
+    backend.resolve()
+    assert np.array_equal(backend.postprocess(1.25), oracle_lib.postprocess(backend.read_image(), 1.25))
+
+
+@pytest.mark.parametrize("w,h,n", [(64, 32, 16), (37, 19, 33), (1, 1, 1), (512, 256, 128)])
+def test_equirect_to_cube_bit_exact(backend, cornell, w, h, n):
+    backend.scene_upload(cornell)
+    rng = np.random.default_rng(w + n)
+    img = np.exp(rng.uniform(-6, 6, (h, w, 4))).astype(np.float32)
+    backend.env_from_equirect(img, n)
+    got = backend.read_env()
+    want = oracle_lib.equirect_to_cube(img, n)
+    assert got.shape == (6, n, n, 4) and np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("params", [(3.14, 0.0, 0.0), (2.0, 1.1, 0.7), (8.0, 5.0, 1.5)])
+def test_preetham_sky_bit_exact(backend, cornell, params):
+    backend.scene_upload(cornell)
+    backend.env_preetham(*params, face_size=96)
+    assert np.array_equal(bits(backend.read_env()), bits(oracle_lib.preetham_sky(*params, 96)))
+
+
+def test_tracing_under_a_converted_environment(backend, cornell, cameras):
+    """Environment made on the GPU from a lat-long image, then path traced: same bits as the oracle tracing
+    under the oracle's conversion of the same image."""
+    import copy
+    rng = np.random.default_rng(9)
+    img = np.exp(rng.uniform(-2, 3, (32, 64, 4))).astype(np.float32)
+    sc = copy.copy(cornell)
+    sc.env = oracle_lib.equirect_to_cube(img, 32)
+    W, H = 96, 80
+    p = Params.reference(spp_per_frame=2, max_bounces=4)
+    backend.scene_upload(cornell)
+    backend.build_accel()
+    backend.env_from_equirect(img, 32)
+    backend.resize(W, H)
+    backend.set_camera(cameras["512x512"])
+    backend.set_params(p)
+    o = oracle_lib.Oracle(sc)
+    o.resize(W, H)
+    o.set_camera(cameras["512x512"])
+    o.set_params(p)
+    for f in (1, 2, 3):
+        backend.trace(f)
+        o.trace(f)
+    assert np.array_equal(bits(backend.read_image()), bits(o.read_image()))
+    with pytest.raises(BackendError):
+        backend.env_preetham(3.0, 0.0, 0.0, face_size=0)

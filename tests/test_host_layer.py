@@ -165,3 +165,79 @@ def test_layer_frame_sequencing(tmp_path):
     layer.OnUpdate()
     assert layer.FrameIndex == 1
     layer.close()
+
+
+# ---- image files ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rle", [True, False])
+@pytest.mark.parametrize("size", [(16, 8), (37, 5), (7, 3), (300, 2)])
+def test_hdr_reader_matches_the_python_reader(tmp_path, rle, size):
+    """No .hdr ships with the reference (its graveyard_pathways_4k.hdr is absent), so the files are made here."""
+    from tests import hdr_py
+    w, h = size
+    rng = np.random.default_rng(w * 31 + h)
+    rgb = np.exp(rng.uniform(-12, 12, (h, w, 3)))
+    rgb[0, : w // 2] = rgb[0, 0]            # long runs for the run-length coder
+    rgb[-1, 0] = 0.0
+    rgbe = hdr_py.float_to_rgbe(rgb)
+    path = tmp_path / "env.hdr"
+    hdr_py.write_hdr(path, rgbe, rle=rle)
+    got = host.load_hdr(path)
+    want = hdr_py.read_hdr(path)
+    assert got.shape == (h, w, 4) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.all(got[..., 3] == 1.0) and np.all(got[-1, 0, :3] == 0.0)
+    brightest = rgb.max(-1)
+    lit = brightest > 0
+    assert np.abs(got[..., :3].max(-1)[lit] / brightest[lit] - 1.0).max() < 0.01     # 8-bit mantissa of the brightest channel
+
+
+def test_hdr_reader_errors(tmp_path):
+    p = tmp_path / "bad.hdr"
+    p.write_bytes(b"P6\n1 1\n255\n\x00\x00\x00")
+    with pytest.raises(RuntimeError):
+        host.load_hdr(p)
+    p.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 4 +X 4\n\x01\x02")
+    with pytest.raises(RuntimeError):
+        host.load_hdr(p)
+    with pytest.raises(RuntimeError):
+        host.load_hdr(tmp_path / "missing.hdr")
+
+
+def test_ppm_writer(tmp_path):
+    img = np.arange(5 * 3 * 4, dtype=np.uint8).reshape(3, 5, 4)
+    path = tmp_path / "out.ppm"
+    host.write_ppm(path, img)
+    data = path.read_bytes()
+    assert data.startswith(b"P6\n5 3\n255\n")
+    assert data[len(b"P6\n5 3\n255\n"):] == img[..., :3].tobytes()
+
+
+@pytest.mark.gpu
+def test_layer_post_processing_and_radiance_map(tmp_path):
+    """OnRender ends with the post-processing pass (RayTracingLayer.cpp:421, exposure 0.8 by default); a radiance
+    map loaded from a .hdr file restarts the accumulation and lights the scene."""
+    from tests import hdr_py, oracle_lib
+    path = write_gltf(tmp_path)
+    src = host.MeshSource(path)
+    cam = host.camera_spec(position=(2.0, 3.0, 8.0), target=(2.0, 3.0, 3.0))
+    layer = host.RayTracingLayer(src, camera=cam)
+    layer.SetParams(Params.reference(spp_per_frame=2, max_bounces=3))
+    layer.SetViewportSize(40, 24)
+    for _ in range(3):
+        layer.OnUpdate(); layer.OnRender()
+    img = layer.ReadImage()
+    assert np.array_equal(layer.ReadPostProcessed(), oracle_lib.postprocess(img, 0.8))
+    layer.SetPostProcessing(True, 2.0)
+    layer.OnUpdate(); layer.OnRender()
+    assert np.array_equal(layer.ReadPostProcessed(), oracle_lib.postprocess(layer.ReadImage(), 2.0))
+    host.write_ppm(tmp_path / "frame.ppm", layer.ReadPostProcessed())
+    assert (tmp_path / "frame.ppm").stat().st_size == len(b"P6\n40 24\n255\n") + 40 * 24 * 3
+    # a dark red sky: frame index restarts, and the sky colour shows in the pixels that miss everything
+    sky = np.zeros((16, 32, 3))
+    sky[..., 0] = 0.25
+    hdr_py.write_hdr(tmp_path / "sky.hdr", hdr_py.float_to_rgbe(sky))
+    layer.SetRadianceMap(tmp_path / "sky.hdr", 16)
+    assert layer.FrameIndex == 1
+    layer.OnUpdate(); layer.OnRender()
+    img = layer.ReadImage()
+    assert img[..., 0].max() > 0 and np.all(img[..., 1:3] <= img[..., 0:1] + 1e-6)
+    layer.close()

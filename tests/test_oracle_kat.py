@@ -438,3 +438,152 @@ def test_golden_cornell_radiance(cornell, cameras):
     for f in range(1, 18):
         o.trace(f)
     assert np.array_equal(o.read_accum().view(np.uint32), want.view(np.uint32))
+
+
+# ---- compute passes around the path tracer (oracle/passes.h) --------------------------------------------------
+def ulp_err(got, want64):
+    got = np.asarray(got, np.float64)
+    spacing = np.spacing(np.abs(want64).astype(np.float32)).astype(np.float64)
+    return np.abs(got - want64) / spacing
+
+
+def test_det_atan2_acos_tan_accuracy():
+    rng = np.random.default_rng(5)
+    y = rng.normal(size=200000).astype(np.float32) * np.exp(rng.uniform(-20, 20, 200000)).astype(np.float32)
+    x = rng.normal(size=200000).astype(np.float32) * np.exp(rng.uniform(-20, 20, 200000)).astype(np.float32)
+    got = oracle_lib.det_math(5, y, x)
+    assert ulp_err(got, np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() <= 3.0
+    # axes and signs
+    for yy, xx, want in ((0.0, 1.0, 0.0), (1.0, 0.0, math.pi / 2), (0.0, -1.0, math.pi), (-1.0, 0.0, -math.pi / 2), (-0.0, -1.0, -math.pi),
+                         (1.0, 1.0, math.pi / 4), (0.0, 0.0, 0.0)):
+        assert abs(float(oracle_lib.det_math(5, [yy], [xx])[0]) - want) < 3e-7
+    c = rng.uniform(-1, 1, 200000).astype(np.float32)
+    got = oracle_lib.det_math(6, c)
+    err = np.abs(got.astype(np.float64) - np.arccos(c.astype(np.float64)))
+    assert err.max() < 6e-7                       # absolute: acos is ill-conditioned at +-1
+    assert oracle_lib.det_math(6, [1.0, -1.0, 1.5, -7.0]).tolist() == pytest.approx([0.0, math.pi, 0.0, math.pi], abs=3e-7)
+    t = rng.uniform(-1.5, 1.5, 100000).astype(np.float32)
+    assert ulp_err(oracle_lib.det_math(7, t), np.tan(t.astype(np.float64))).max() <= 4.0
+
+
+def test_round_to_half_equals_numpy_float16():
+    rng = np.random.default_rng(6)
+    x = (rng.normal(size=400000) * np.exp(rng.uniform(-30, 14, 400000))).astype(np.float32)
+    x[:12] = [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, np.inf, 6.1e-5]
+    ties = (np.arange(2048, dtype=np.float32) + 1024.0) * np.float32(2.0 ** -10) + np.float32(2.0 ** -11)   # exact halfway cases
+    x = np.concatenate([x, ties, -ties])
+    got = oracle_lib.det_math(8, x)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def np_postprocess(rgb, exposure):
+    """float64 restatement of PostProcessing.glsl:14-55, written from the shader text."""
+    m1 = np.array([[0.59719, 0.07600, 0.02840], [0.35458, 0.90834, 0.13383], [0.04823, 0.01566, 0.83777]]).T   # columns as given
+    m2 = np.array([[1.60475, -0.10208, -0.00327], [-0.53108, 1.10813, -0.07276], [-0.07367, -0.00605, 1.07602]]).T
+    v = (rgb.astype(np.float64) * exposure) @ m1.T
+    a = v * (v + 0.0245786) - 0.000090537
+    b = v * (0.983729 * v + 0.4329510) + 0.238081
+    c = np.clip((a / b) @ m2.T, 0.0, 1.0)
+    return c ** (1.0 / 2.2)
+
+
+def test_postprocess_against_float64_restatement():
+    rng = np.random.default_rng(7)
+    img = np.exp(rng.uniform(-8, 4, (64, 64, 4))).astype(np.float32)
+    img[0, 0] = 0.0
+    img[0, 1] = [1e6, 1e6, 1e6, 1.0]
+    got = oracle_lib.postprocess(img, 0.8)
+    want = np_postprocess(img[..., :3], np.float32(0.8)) * 255.0
+    assert np.all(got[..., 3] == 255)
+    assert np.abs(got[..., :3].astype(np.float64) - want).max() <= 0.5 + 2e-3      # rounding + float32 evaluation
+    assert got[0, 0, :3].tolist() == [0, 0, 0]             # a/b < 0 at black: clamped
+    assert got[0, 1, :3].min() >= 250
+    # NaN and negative radiance do not crash and give defined bytes
+    bad = np.array([[[np.nan, -1.0, np.inf, 1.0]]], np.float32)
+    assert oracle_lib.postprocess(bad, 0.8).shape == (1, 1, 4)
+
+
+def cube_dirs(n):
+    """Direction of every cube texel per GetCubeMapTexCoord (EquirectangularToCubeMap.glsl:11-25), float64."""
+    g = np.arange(n, dtype=np.float64) / n
+    ux, uy = np.meshgrid(2.0 * g - 1.0, 2.0 * (1.0 - g) - 1.0)
+    one = np.ones_like(ux)
+    faces = [(one, uy, -ux), (-one, uy, ux), (ux, one, -uy), (ux, -one, uy), (ux, uy, one), (-ux, uy, -one)]
+    d = np.stack([np.stack(f, -1) for f in faces])
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def test_equirect_to_cube_properties():
+    n = 16
+    const = np.tile(np.array([0.3, 1.7, 100.1, 1.0], np.float32), (8, 16, 1))
+    cube = oracle_lib.equirect_to_cube(const, n)
+    want = const[0, 0].astype(np.float16).astype(np.float32)          # the cube is rgba16f
+    assert np.array_equal(cube.reshape(-1, 4), np.tile(want, (6 * n * n, 1)))
+    # a smooth image of the direction: cube texel = image evaluated at its (u, v), up to filtering and binary16
+    w, h = 512, 256
+    u = (np.arange(w) + 0.5) / w
+    v = (np.arange(h) + 0.5) / h
+    img = np.zeros((h, w, 4), np.float32)
+    img[..., 0] = np.cos(2 * np.pi * u)[None, :] * 0.5 + 1.0
+    img[..., 1] = v[:, None]
+    img[..., 2] = 2.0
+    img[..., 3] = 1.0
+    cube = oracle_lib.equirect_to_cube(img, n).astype(np.float64)
+    d = cube_dirs(n)
+    uu = np.arctan2(d[..., 2], d[..., 0]) / (2 * 3.141592) + 0.5
+    vv = np.arccos(d[..., 1]) / 3.141592
+    assert np.abs(cube[..., 0] - (np.cos(2 * np.pi * uu) * 0.5 + 1.0)).max() < 2e-3
+    assert np.abs(cube[..., 1] - vv).max() < 2e-3
+    assert np.all(cube[..., 2] == 2.0)
+    # +Y face looks at the top row of the image, -Y at the bottom row
+    assert cube[2, n // 2, n // 2, 1] < 0.1 and cube[3, n // 2, n // 2, 1] > 0.9
+
+
+def np_preetham(d, turbidity, azimuth, inclination):
+    """float64 restatement of PreethamSky.glsl:35-146 for unit directions d, written from the shader text."""
+    PI = 3.14159265359
+    t = turbidity
+    s = np.array([np.sin(inclination) * np.cos(azimuth), np.cos(inclination), np.sin(inclination) * np.sin(azimuth)])
+    s = s / np.linalg.norm(s)
+    A = np.array([0.1787 * t - 1.4630, -0.0193 * t - 0.2592, -0.0167 * t - 0.2608])
+    B = np.array([-0.3554 * t + 0.4275, -0.0665 * t + 0.0008, -0.0950 * t + 0.0092])
+    Cc = np.array([-0.0227 * t + 5.3251, -0.0004 * t + 0.2125, -0.0079 * t + 0.2102])
+    D = np.array([0.1206 * t - 2.5771, -0.0641 * t - 0.8989, -0.0441 * t - 1.6537])
+    E = np.array([-0.0670 * t + 0.3703, -0.0033 * t + 0.0452, -0.0109 * t + 0.0529])
+    thS = np.arccos(max(s[1], 0.0))
+    thE = np.arccos(np.maximum(d[..., 1], 0.0))
+    gam = np.arccos(np.clip(np.maximum(d @ s, 0.0), -1, 1))
+    chi = (4.0 / 9.0 - t / 120.0) * (PI - 2.0 * thS)
+    Yz = (4.0453 * t - 4.9710) * np.tan(chi) - 0.2155 * t + 2.4192
+    th2, th3 = thS * thS, thS ** 3
+    xz = (0.00165 * th3 - 0.00375 * th2 + 0.00209 * thS) * t * t + (-0.02903 * th3 + 0.06377 * th2 - 0.03202 * thS + 0.00394) * t + \
+         (0.11693 * th3 - 0.21196 * th2 + 0.06052 * thS + 0.25886)
+    yz = (0.00275 * th3 - 0.00610 * th2 + 0.00317 * thS) * t * t + (-0.04214 * th3 + 0.08970 * th2 - 0.04153 * thS + 0.00516) * t + \
+         (0.15346 * th3 - 0.26756 * th2 + 0.06670 * thS + 0.26688)
+
+    def perez(theta, gamma):
+        theta, gamma = np.asarray(theta)[..., None], np.asarray(gamma)[..., None]
+        with np.errstate(over="ignore", divide="ignore"):
+            return (1.0 + A * np.exp(B / np.cos(theta))) * (1.0 + Cc * np.exp(D * gamma) + E * np.cos(gamma) ** 2)
+
+    Yp = np.array([Yz, xz, yz]) * (perez(thE, gam) / perez(0.0, thS))
+    Y, x, y = Yp[..., 0], Yp[..., 1], Yp[..., 2]
+    X = x * (Y / y)
+    Z = (1.0 - x - y) * (Y / y)
+    M = np.array([[2.3706743, -0.9000405, -0.4706338], [-0.5138850, 1.4253036, 0.0885814], [0.0052982, -0.0146949, 1.0093968]])
+    return np.stack([X, Y, Z], -1) @ M.T * 0.05
+
+
+@pytest.mark.parametrize("params", [(3.14, 0.0, 0.0), (2.2, 1.0, 0.9), (6.0, 4.0, 1.3)])
+def test_preetham_sky_against_float64_restatement(params):
+    n = 24
+    cube = oracle_lib.preetham_sky(*params, n)
+    assert np.all(cube[..., 3] == 1.0)
+    want = np_preetham(cube_dirs(n), *[float(np.float32(p)) for p in params])
+    upper = cube_dirs(n)[..., 1] > 0.05            # below the horizon cos(theta) = 0: the shader divides by it
+    got = cube[..., :3].astype(np.float64)
+    scale = np.abs(want[upper]).max()
+    assert np.isfinite(got[upper]).all()
+    assert np.abs(got[upper] - want[upper]).max() < 2e-4 * scale
