@@ -188,7 +188,7 @@ int pt_create(int device_ordinal, pt_ctx** out)
     uint32_t hwq = 4;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = (uint32_t)atoi(e);
     ctx->chains = hwq >= 8 ? 8u : 4u;
-    if (const char* e = getenv("PT_DEFER")) ctx->defer_rays = atoi(e) != 0;
+    if (const char* e = getenv("PT_DEFER")) { int v = atoi(e); ctx->defer_rounds = v < 0 ? 0u : (v > 8 ? 8u : (uint32_t)v); }
     if (const char* e = getenv("PT_CHAINS")) {
         uint32_t c = (uint32_t)atoi(e);
         if (c >= 1 && c <= PT_MAX_CHAINS && PT_SHARDS % c == 0) ctx->chains = c;
@@ -212,6 +212,7 @@ void pt_destroy(pt_ctx* ctx)
     free_images(ctx);
     (void)dev_free(ctx->d_counts);
     (void)dev_free(ctx->d_spill);
+    (void)dev_free(ctx->d_suspend);
     (void)dev_free(ctx->d_wave_trace);
     (void)dev_free(ctx->d_total_rays);
     (void)dev_free(ctx->d_stats);
@@ -444,7 +445,7 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
     if (!ctx->camera_set) return set_error(ctx, PT_ERR_INVALID, "pt_trace: call pt_set_camera first");
     if (frame_index == 0) return set_error(ctx, PT_ERR_INVALID, "pt_trace: frame_index is 1-based");
     PT_HIP(ctx, hipSetDevice(ctx->device));
-    uint32_t rounds = ctx->params.spp_per_frame * ctx->params.max_bounces + 1u;
+    uint32_t rounds = ctx->params.spp_per_frame * ctx->params.max_bounces + ctx->defer_rounds;
     if (rounds + 1 > ctx->counts_cap) {
         PT_SYNC(ctx);
         (void)dev_free(ctx->d_counts);

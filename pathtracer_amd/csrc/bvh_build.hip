@@ -199,7 +199,10 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals, const float4* 
 
 
 // ---- agglomerative build (parallel locally-ordered clustering) ------------------------------------
-static constexpr int PLOC_RADIUS = 16;
+#ifndef PT_PLOC_RADIUS
+#define PT_PLOC_RADIUS 16
+#endif
+static constexpr int PLOC_RADIUS = PT_PLOC_RADIUS;
 static constexpr int PLOC_BLOCK = 256;
 
 __global__ void k_ploc_init(int n, const uint32_t* __restrict__ vals, const float4* __restrict__ tlo, const float4* __restrict__ thi,

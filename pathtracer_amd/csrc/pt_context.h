@@ -74,7 +74,9 @@ struct pt_ctx {
     uint32_t shard_cap = 0;         // ray-queue slots per shard
     uint32_t* d_counts = nullptr;   // per chain: rounds + 1 rows of queue sizes (one per shard of the chain), then as many rows of fetch cursors
     uint32_t counts_cap = 0;
-    bool defer_rays = true;         // traversal launches hand their last few rays on to the next round (PT_DEFER=0: off)
+    uint32_t defer_rounds = 2;      // rounds a path may fall behind because its ray was suspended at the tail of a launch (PT_DEFER; 0: off)
+    uint32_t* d_suspend = nullptr;  // suspended traversals, [chain][2][shard of the chain][slot][PT_SUSPEND_WORDS]
+    size_t suspend_words = 0;
     uint2* d_spill = nullptr;       // traversal stack spill area, [chain][wave][entry][lane]
     uint32_t spill_waves = 0;
     unsigned long long* d_wave_trace = nullptr;   // PT_WAVE_TRACE=<file>: per-wave timeline of the extend launches

@@ -17,9 +17,10 @@
 // mostly empty.  The ray travels to the testing lane, and the result back, through lane permutes.
 //
 // Tail: when the queue has run dry a wave soon walks a handful of long rays with most lanes idle, and the
-// launch lasts until the last of them is done.  Such a wave instead defers those rays (where the caller allows
-// it): they are traced again from the start by the next launch, among its first rays and in full waves.  The
-// closest hit does not depend on when or by whom a ray is traced, so results are unchanged.
+// launch lasts until the last of them is done.  Such a wave instead suspends those rays (where the caller allows
+// it): best hit so far, position and stack go to a record in global memory, and the next launch picks the ray up
+// among its first rays, in a full wave, and carries on where it stopped.  The closest hit does not depend on when
+// or by whom a ray is traced, so results are unchanged.
 //
 // Stack: the top PT_STACK_LDS entries of each lane live in an LDS ring (one column per lane,
 // conflict free); deeper entries move in blocks to a per-wave spill area in global memory, laid
@@ -44,8 +45,11 @@ namespace ptd {
 #define PT_LEAF_MIN 24     // lanes with a pending leaf that trigger the triangle phase while others still walk nodes
 #endif
 #ifndef PT_CUT_LANES
-#define PT_CUT_LANES 8     // a wave whose queue ran dry defers its rays once no more than this many are in flight
+#define PT_CUT_LANES 16    // a wave whose queue ran dry suspends its rays once no more than this many are in flight
 #endif
+#define PT_RAY_CUTTABLE 1u // fetch flags: the ray may be suspended; the ray resumes a suspended traversal
+#define PT_RAY_RESUME 2u
+#define PT_SUSPEND_WORDS (16 + 2 * PT_STACK_MAX)   // words of a suspended traversal: 16 of state, then the stack
 #define PT_CUR_NONE 0x7FFFFFFFu   // s.cur when the stack ran empty; node indices are below, leaf references above
 #define PT_OWNER_BYTES 256        // LDS bytes per wave for the triangle phase's work list
 
@@ -277,6 +281,28 @@ PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack
     return trav_pop(s, lds_stack, stride, ovf);
 }
 
+// suspended traversal: [0] best.t [1] best.tri [2] bV [3] bW [4] bdet [5] cur [6] cur_key [7] pend [8] sp, then sp stack entries
+PT_DEV void trav_save(const Trav& s, uint32_t* rec, const uint2* lds_stack, int stride, const uint2* ovf)
+{
+    rec[0] = f2u(s.best.t); rec[1] = s.best.tri; rec[2] = f2u(s.bV); rec[3] = f2u(s.bW); rec[4] = f2u(s.bdet);
+    rec[5] = s.cur; rec[6] = f2u(s.cur_key); rec[7] = s.pend; rec[8] = (uint32_t)s.sp;
+    uint2* st = reinterpret_cast<uint2*>(rec + 16);
+    for (int k = 0; k < s.base; k++) st[k] = ovf[k * 64];
+    for (int k = s.base; k < s.sp; k++) st[k] = lds_stack[(k & (PT_STACK_LDS - 1)) * stride];
+}
+
+// call after trav_init of the same ray
+PT_DEV void trav_restore(Trav& s, const uint32_t* rec, uint2* lds_stack, int stride, uint2* ovf)
+{
+    s.best.t = u2f(rec[0]); s.best.tri = rec[1]; s.bV = u2f(rec[2]); s.bW = u2f(rec[3]); s.bdet = u2f(rec[4]);
+    s.cur = rec[5]; s.cur_key = u2f(rec[6]); s.pend = rec[7]; s.sp = (int)rec[8];
+    // the top of the stack goes to the LDS ring, whole blocks below it to the spill column
+    s.base = s.sp > PT_STACK_LDS ? ((s.sp - PT_STACK_BLK - 1) & ~(PT_STACK_BLK - 1)) : 0;
+    const uint2* st = reinterpret_cast<const uint2*>(rec + 16);
+    for (int k = 0; k < s.base; k++) ovf[k * 64] = st[k];
+    for (int k = s.base; k < s.sp; k++) lds_stack[(k & (PT_STACK_LDS - 1)) * stride] = st[k];
+}
+
 // lanes below this one among the set bits of mask
 PT_DEV uint32_t lanes_below(unsigned long long mask)
 {
@@ -360,14 +386,15 @@ PT_DEV void finish_hit(Trav& s)
     }
 }
 
-// Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue and says whether the ray may be
-// deferred; emit(i, hit) stores its result; defer(i) hands ray i back untraced (see PT_CUT_LANES).
+// Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue and returns PT_RAY_* flags;
+// emit(i, hit) stores its result; suspend(i, record) hands ray i on with its traversal saved (see PT_CUT_LANES),
+// resume_record(i) is where a ray flagged PT_RAY_RESUME finds the traversal it was suspended with.
 // its result; *cursor hands out queue indices (must be 0 at launch), n = queue length.
 // lds_stack points at this lane's column: entry k is lds_stack[k * stride]; ovf points at this lane's
 // column of the wave's global spill area: entry k is ovf[k * 64]; owner is the wave's LDS work list.
-template <bool STATS, bool CUT, class Fetch, class Emit, class Defer>
+template <bool STATS, bool CUT, class Fetch, class Emit, class Suspend, class ResumeRecord>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
-                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint8_t* owner, Fetch fetch, Emit emit, Defer defer,
+                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint8_t* owner, Fetch fetch, Emit emit, Suspend suspend, ResumeRecord resume_record,
                        uint32_t& stat_nodes, uint32_t& stat_tris, WaveStats* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -396,8 +423,10 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
                 if (i < n) {
                     v3 o, d;
                     float tmin, tmax;
-                    cuttable = fetch(i, o, d, tmin, tmax);
+                    const uint32_t flags = fetch(i, o, d, tmin, tmax);
+                    cuttable = (flags & PT_RAY_CUTTABLE) != 0;
                     trav_init(s, o, d, tmin, tmax);
+                    if (CUT && (flags & PT_RAY_RESUME)) trav_restore(s, resume_record(i), lds_stack, stride, ovf);
                     my = i;
                     ray_steps = 0;
                     if (num_tris == 0) emit(my, s.best);
@@ -412,7 +441,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         unsigned long long hasm = __ballot(has);
         if (CUT && exhausted && hasm != 0 && (uint32_t)__popcll(hasm) <= PT_CUT_LANES) {
             // the tail of a launch: hand the last few rays back instead of walking them with a nearly empty wave
-            if (has && cuttable) { defer(my); has = false; }
+            if (has && cuttable) { suspend(my, s, lds_stack, stride, ovf); has = false; }
             hasm = __ballot(has);
         }
         if (hasm == 0) {

@@ -133,18 +133,22 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
     }
 }
 
-// hit record of a ray that was handed on to the next round untraced
+// hit record of a ray that was suspended and handed on to the next round
 static constexpr uint32_t DEFERRED = 0xFFFFFFFEu;
-// rayD.w of a ray that must be traced to the end (its path has been deferred once already)
-#define PT_RAY_NO_DEFER 1.0f
+// rayD.w (as bits): rounds the path is behind schedule in the low byte, RAY_RESUMES if the ray continues a suspended traversal
+static constexpr uint32_t RAY_LAG_MASK = 0xFFu, RAY_RESUMES = 0x100u;
 
 struct ExtendArgs {
     float tmin, tmax;
     const uint32_t* counts;     // queue sizes of this round, one per shard of the chain
     uint32_t* cursors;          // fetch cursors of this round
-    uint32_t* next_counts;      // queue sizes of the next round (deferred rays go to its front); nullptr in launches that do not defer
-    uint32_t* deferred;         // running count of deferred rays of the chain's frame
+    uint32_t* next_counts;      // queue sizes of the next round (suspended rays go to its front); nullptr in launches that do not suspend
+    uint32_t* deferred;         // running count of suspended rays of the chain's frame
     uint32_t shard0, nshards, shard_cap;
+    uint32_t max_lag;           // a path may fall this many rounds behind
+    uint32_t susp_cap;          // suspended-traversal records per shard
+    const uint32_t* susp_in;    // records of the rays suspended by the previous round, [shard of the chain][slot][PT_SUSPEND_WORDS]
+    uint32_t* susp_out;         // records for the next round
     const float4* rayO; const float4* rayD;
     float4* next_rayO; float4* next_rayD;
     float4* hits;
@@ -167,11 +171,12 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, ExtendArgs a
         d = V3(rd.x, rd.y, rd.z);
         tn = a.tmin;
         tx = a.tmax;
-        return rd.w != PT_RAY_NO_DEFER;
+        uint32_t w = f2u(rd.w);
+        return ((w & RAY_LAG_MASK) < a.max_lag ? PT_RAY_CUTTABLE : 0u) | ((w & RAY_RESUMES) ? PT_RAY_RESUME : 0u);
     };
     auto emit = [&](uint32_t i, const HitRec& h) { a.hits[base + i] = make_float4(h.t, h.u, h.v, u2f(h.tri)); };
-    auto defer = [&](uint32_t i) {
-        // called by all lanes that defer, inside one branch: one queue slot each at the front of the next round
+    auto suspend = [&](uint32_t i, const Trav& s, const uint2* lds_stack, int stride, const uint2* ovf) {
+        // called by all lanes that suspend, inside one branch: one queue slot each at the front of the next round
         unsigned long long m = __ballot(true);
         uint32_t lane = threadIdx.x & 63u;
         int leader = __ffsll((long long)m) - 1;
@@ -181,14 +186,16 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, ExtendArgs a
             atomicAdd(a.deferred, (uint32_t)__popcll(m));
         }
         slot0 = __shfl(slot0, leader);
-        uint32_t out = base + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        uint32_t slot = slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));     // < susp_cap: a wave suspends at most PT_CUT_LANES rays
         float4 ro = a.rayO[base + i], rd = a.rayD[base + i];
-        a.next_rayO[out] = ro;
-        a.next_rayD[out] = make_float4(rd.x, rd.y, rd.z, PT_RAY_NO_DEFER);
+        a.next_rayO[base + slot] = ro;
+        a.next_rayD[base + slot] = make_float4(rd.x, rd.y, rd.z, u2f(((f2u(rd.w) & RAY_LAG_MASK) + 1u) | RAY_RESUMES));
         a.hits[base + i] = make_float4(0.0f, 0.0f, 0.0f, u2f(DEFERRED));
+        trav_save(s, a.susp_out + ((size_t)ls * a.susp_cap + slot) * PT_SUSPEND_WORDS, lds_stack, stride, ovf);
     };
+    auto resume_record = [&](uint32_t i) { return a.susp_in + ((size_t)ls * a.susp_cap + i) * PT_SUSPEND_WORDS; };
     trace_wave<STATS, CUT>(sc.nodes, sc.tris, sc.num_tris, n, &a.cursors[ls], stack + threadIdx.x, EXT_BLOCK,
-                           a.spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner, fetch, emit, defer, sn, st, STATS ? &ws : nullptr);
+                           a.spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner, fetch, emit, suspend, resume_record, sn, st, STATS ? &ws : nullptr);
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
@@ -368,11 +375,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
         bool alive = false;
         v3 o = V3(0.0f), d = V3(0.0f);
         uint32_t pixel = 0;
-        float no_defer = 0.0f;
-        if (valid && f2u(q.hits[slot].w) == DEFERRED) valid = false;     // the traversal kernel passed this ray on itself
+        float lag_bits = 0.0f;
+        if (valid && f2u(q.hits[slot].w) == DEFERRED) valid = false;     // suspended: the traversal kernel has queued it for the next round
         if (valid) {
             float4 ro = q.rayO_in[slot], rd = q.rayD_in[slot], h = q.hits[slot];
-            no_defer = rd.w;
+            lag_bits = u2f(f2u(rd.w) & RAY_LAG_MASK);     // the path stays as far behind as it is
             pixel = f2u(ro.w);
             o = V3(ro.x, ro.y, ro.z);
             d = V3(rd.x, rd.y, rd.z);
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
         uint32_t out = shard * q.shard_cap + wave_append(alive, &q.counts[(round + 1) * q.nshards + ls]);
         if (alive) {
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
-            q.rayD_out[out] = make_float4(d.x, d.y, d.z, no_defer);
+            q.rayD_out[out] = make_float4(d.x, d.y, d.z, lag_bits);
         }
     }
 }
@@ -504,8 +511,8 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
 {
     const pt_params& pp = ctx->params;
     uint32_t npix = ctx->width * ctx->height;
-    // one round more than the longest path needs: a path whose ray was deferred runs one round late
-    const uint32_t rounds = pp.spp_per_frame * pp.max_bounces + (ctx->defer_rays ? 1u : 0u);
+    // more rounds than the longest path needs: a path falls a round behind each time its ray is suspended
+    const uint32_t rounds = pp.spp_per_frame * pp.max_bounces + ctx->defer_rounds;
     TraceParams P;
     P.width = ctx->width; P.height = ctx->height;
     P.spp = pp.spp_per_frame; P.max_bounces = pp.max_bounces; P.rr_depth = pp.rr_depth;
@@ -570,6 +577,19 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         int rc = ensure_spill(ctx, ext_blocks * chains);
         if (rc) return rc;
     }
+    // records of suspended traversals: per chain two pools (the round's own and the next round's), per shard one
+    // record for each ray the shard's waves can suspend in a launch
+    const uint32_t susp_cap = (ext_blocks / spc) * PT_CUT_LANES;
+    {
+        size_t need = (size_t)chains * 2 * spc * susp_cap * PT_SUSPEND_WORDS;
+        if (ctx->defer_rounds && need > ctx->suspend_words) {
+            PT_SYNC(ctx);
+            if (ctx->d_suspend) (void)hipFree(ctx->d_suspend);
+            ctx->d_suspend = nullptr;
+            PT_HIP(ctx, hipMalloc((void**)&ctx->d_suspend, need * sizeof(uint32_t)));
+            ctx->suspend_words = need;
+        }
+    }
     if (counting && window_start) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 128, ctx->stream));
         ctx->main_dirty = true;
@@ -627,7 +647,11 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
             ExtendArgs ea;
             ea.tmin = P.tmin; ea.tmax = P.tmax;
             ea.counts = counts + r * spc; ea.cursors = cursors + r * spc;
-            ea.next_counts = (ctx->defer_rays && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
+            ea.next_counts = (ctx->defer_rounds && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
+            ea.max_lag = ctx->defer_rounds;
+            ea.susp_cap = susp_cap;
+            ea.susp_in = ctx->d_suspend + ((size_t)(c * 2 + in) * spc) * susp_cap * PT_SUSPEND_WORDS;
+            ea.susp_out = ctx->d_suspend + ((size_t)(c * 2 + out) * spc) * susp_cap * PT_SUSPEND_WORDS;
             ea.deferred = deferred;
             ea.shard0 = q.shard0; ea.nshards = spc; ea.shard_cap = ctx->shard_cap;
             ea.rayO = ctx->d_rayO[in]; ea.rayD = ctx->d_rayD[in];
@@ -682,14 +706,14 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
             d = V3(rd.x, rd.y, rd.z);
             tn = ro.w;
             tx = rd.w;
-            return false;
+            return 0u;
         },
         [&](uint32_t i, const HitRec& h) {
             uint32_t* o = out + (size_t)i * 5;
             if (h.tri == MISS) { o[0] = f2u(h.t); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }   // h.t is still tmax
             else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = sc.tris[h.tri].submesh; o[4] = sc.tris[h.tri].prim; }
         },
-        [&](uint32_t) {}, sn, st);
+        [&](uint32_t, const Trav&, const uint2*, int, const uint2*) {}, [&](uint32_t) { return (const uint32_t*)nullptr; }, sn, st);
     atomicAdd(&stats[0], (unsigned long long)sn);
     atomicAdd(&stats[1], (unsigned long long)st);
 }
