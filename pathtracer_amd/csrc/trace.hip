@@ -138,6 +138,12 @@ static constexpr uint32_t DEFERRED = 0xFFFFFFFEu;
 // rayD.w (as bits): rounds the path is behind schedule in the low byte, RAY_RESUMES if the ray continues a suspended traversal
 static constexpr uint32_t RAY_LAG_MASK = 0xFFu, RAY_RESUMES = 0x100u;
 
+// 5 waves per SIMD need at most 96 VGPRs
+#ifndef PT_EXT_WAVES_PER_SIMD
+#define PT_EXT_WAVES_PER_SIMD 5
+#endif
+#define PT_EXT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES_PER_SIMD, PT_EXT_WAVES_PER_SIMD)))
+
 struct ExtendArgs {
     float tmin, tmax;
     const uint32_t* counts;     // queue sizes of this round, one per shard of the chain
@@ -156,7 +162,7 @@ struct ExtendArgs {
 };
 
 template <bool STATS, bool CUT>
-__global__ void __launch_bounds__(EXT_BLOCK) k_extend(SceneView sc, ExtendArgs a, unsigned long long* stats, unsigned long long* wave_trace)
+__global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneView sc, ExtendArgs a, unsigned long long* stats, unsigned long long* wave_trace)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     __shared__ uint8_t owner[PT_OWNER_BYTES];
