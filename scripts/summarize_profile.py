@@ -40,6 +40,16 @@ lines += ["", "| kernel | vgpr | agpr | sgpr | lds B | scratch B | workgroup | g
 for r in res:
     if "ptd::" in r[0]:
         lines.append("| %s | %s |" % (short(r[0]), " | ".join(str(x) for x in r[1:])))
+# the bench line printed by the profiled run itself: its event-timed launch average next to rocprof's
+try:
+    bench = [json.loads(l) for l in open(os.path.join(src, "trace.log")) if l.startswith('{"metric"')][-1]
+    rl = bench["roofline"]
+    prod = agg.get("ptd::k_extend<false, true>")
+    lines += ["", "bench.py inside this run: value %.1f %s, roofline.avg_launch_ms %.4f (HIP events, %d launches of the timing window), "
+              "concurrency %.2f; rocprofv3 average of k_extend<false, true> over the whole run: %.4f ms"
+              % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], prod[1] / prod[0] * 1e-3 if prod else float("nan"))]
+except (OSError, IndexError, KeyError, ValueError):
+    pass
 open(os.path.join(out_dir, tag + "_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
 
 pmc = {}
