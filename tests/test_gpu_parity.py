@@ -283,6 +283,21 @@ def test_image_does_not_depend_on_the_chain_count(backend, cornell, cameras, cha
         backend.set_chains(3)
 
 
+@pytest.mark.parametrize("defer", ["0", "1", "4"])
+def test_image_does_not_depend_on_ray_suspension(cornell, cameras, monkeypatch, defer):
+    """PT_DEFER = rounds a path may fall behind because the tail of a traversal launch suspended its ray (default 2;
+    0 = never suspend).  A tiny image on many waves makes nearly every launch all tail."""
+    from pathtracer_amd.backend import Backend
+    monkeypatch.setenv("PT_DEFER", defer)
+    b = Backend(0)
+    try:
+        for W, H, S, B in ((64, 48, 3, 6), (256, 200, 1, 8)):
+            o, rays = render_pair(b, cornell, cameras["512x512"], W, H, (1, 2, 3), spp_per_frame=S, max_bounces=B)
+            assert_same_frame(b, o, rays)
+    finally:
+        b.close()
+
+
 def test_cornell_512_config_and_golden_ids(backend, cornell, cameras):
     # BASELINE configs[0]: Cornell 512x512, 1 spp, 4 bounces
     o, rays = render_pair(backend, cornell, cameras["512x512"], 512, 512, (1, 2), spp_per_frame=1, max_bounces=4)
