@@ -91,11 +91,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
+    # rehearsal on a one-GPU box: PT_BENCH_REHEARSE=1 puts every rank on GPU 0 and reduces through gloo
+    rehearse = os.environ.get("PT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     scene, cam, workload_text = make_workload(args.workload, args.width, args.height, args.detail)
     params = Params.reference(spp_per_frame=1, max_bounces=args.bounces)
