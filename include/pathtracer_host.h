@@ -66,6 +66,12 @@ int pth_layer_read_postprocessed(pth_layer* l, uint8_t* rgba8);   /* m_PostProce
 /* Radiance .hdr (RGBE) reader: *rgba = malloc'ed width*height*4 floats (row 0 = top, alpha 1), free with pth_pixels_free */
 int pth_hdr_load(const char* path, uint32_t* width, uint32_t* height, float** rgba, char* err, size_t errlen);
 void pth_pixels_free(float* rgba);
+/* PNG (non-interlaced) or baseline JPEG -> malloc'ed width*height*4 bytes RGBA8, free with pth_image_free */
+int pth_image_load(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgba8, char* err, size_t errlen);
+void pth_image_free(uint8_t* rgba8);
+/* decodes every glTF image of the mesh that is an external PNG / JPEG file next to the .gltf (what the engine's
+ * MeshSource does on import); returns the number decoded, -1 on error.  Images left undecoded count as absent. */
+int pth_mesh_load_textures(pth_mesh* m, char* err, size_t errlen);
 /* binary PPM (P6) of an RGBA8 image, alpha dropped */
 int pth_ppm_write(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, char* err, size_t errlen);
 

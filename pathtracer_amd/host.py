@@ -18,7 +18,7 @@ EXPORTS = [
     "pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render", "pth_layer_frame_index",
     "pth_layer_read_image", "pth_layer_read_accum", "pth_layer_ray_count", "pth_layer_last_error",
     "pth_layer_set_radiance_map", "pth_layer_set_post_processing", "pth_layer_read_postprocessed",
-    "pth_hdr_load", "pth_pixels_free", "pth_ppm_write",
+    "pth_hdr_load", "pth_pixels_free", "pth_ppm_write", "pth_image_load", "pth_image_free", "pth_mesh_load_textures",
 ]
 
 
@@ -75,6 +75,10 @@ def load_library():
     L.pth_hdr_load.argtypes = [C.c_char_p, up, up, C.POINTER(fp), C.c_char_p, C.c_size_t]
     L.pth_pixels_free.argtypes = [fp]
     L.pth_pixels_free.restype = None
+    L.pth_image_load.argtypes = [C.c_char_p, up, up, C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p, C.c_size_t]
+    L.pth_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.pth_image_free.restype = None
+    L.pth_mesh_load_textures.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.pth_ppm_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_char_p, C.c_size_t]
     L.pth_layer_last_error.restype = C.c_char_p
     _lib = L
@@ -129,6 +133,14 @@ class MeshSource:
     def set_texture(self, i, rgba8):
         t = np.ascontiguousarray(rgba8, np.uint8)
         assert self.L.pth_mesh_set_texture(self.h, i, t.shape[1], t.shape[0], t.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+
+    def load_textures(self):
+        """Decodes the external PNG / JPEG images next to the .gltf; returns how many."""
+        err = C.create_string_buffer(512)
+        n = self.L.pth_mesh_load_textures(self.h, err, len(err))
+        if n < 0:
+            raise RuntimeError(err.value.decode())
+        return n
 
     def set_material(self, i, words):
         m = np.ascontiguousarray(words, np.float32)
@@ -245,6 +257,19 @@ def load_hdr(path):
         return np.ctypeslib.as_array(px, shape=(h.value, w.value, 4)).copy()
     finally:
         L.pth_pixels_free(px)
+
+
+def load_image(path):
+    """PNG or baseline JPEG -> (H, W, 4) uint8 (C++ decoders of the host layer)."""
+    L = load_library()
+    w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    err = C.create_string_buffer(512)
+    if L.pth_image_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px), err, len(err)):
+        raise RuntimeError(err.value.decode())
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, 4)).copy()
+    finally:
+        L.pth_image_free(px)
 
 
 def write_ppm(path, rgba8):

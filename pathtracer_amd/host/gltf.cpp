@@ -312,4 +312,24 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
     if (m_SubMeshes.empty()) throw std::runtime_error("gltf: no triangle primitives in " + path);
 }
 
+size_t MeshSource::LoadTextures()
+{
+    std::string dir;
+    size_t slash = m_Path.find_last_of("/\\");
+    if (slash != std::string::npos) dir = m_Path.substr(0, slash + 1);
+    size_t n = 0;
+    for (TextureData& t : m_Textures) {
+        if (!t.RGBA8.empty() || t.Uri.empty() || t.Uri.compare(0, 5, "data:") == 0) continue;
+        std::string uri = t.Uri;
+        for (size_t k = 0; k + 2 < uri.size(); k++)           // %20 and friends
+            if (uri[k] == '%' && isxdigit((unsigned char)uri[k + 1]) && isxdigit((unsigned char)uri[k + 2])) {
+                uri.replace(k, 3, 1, (char)std::stoi(uri.substr(k + 1, 2), nullptr, 16));
+            }
+        TextureData d = LoadImageFile(dir + uri);
+        t.Width = d.Width; t.Height = d.Height; t.RGBA8 = std::move(d.RGBA8);
+        n++;
+    }
+    return n;
+}
+
 } // namespace ptamd

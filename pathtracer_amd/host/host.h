@@ -90,6 +90,7 @@ public:
     const std::vector<TextureData>& GetTextures() const { return m_Textures; }
     std::vector<TextureData>& GetTextures() { return m_Textures; }
     const std::string& GetPath() const { return m_Path; }
+    size_t LoadTextures();        // decodes the external PNG / JPEG images next to the .gltf; returns how many
 
 private:
     std::string m_Path;
@@ -222,6 +223,10 @@ struct SceneBuffer {                                   // RayTracingLayer.h:26-3
     float padding0 = 0, padding1 = 0, padding2 = 0;
     float AbsorptionFactor[3] = {1, 1, 1};
 };
+
+// image_decode.cpp: PNG (zlib) and baseline JPEG -> RGBA8
+TextureData DecodeImage(const std::vector<uint8_t>& bytes);
+TextureData LoadImageFile(const std::string& path);
 
 // image_io.cpp
 struct HdrImage {

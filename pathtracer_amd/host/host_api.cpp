@@ -200,6 +200,31 @@ int pth_hdr_load(const char* path, uint32_t* width, uint32_t* height, float** rg
     }
 }
 void pth_pixels_free(float* rgba) { free(rgba); }
+
+int pth_image_load(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgba8, char* err, size_t errlen)
+{
+    try {
+        ptamd::TextureData t = ptamd::LoadImageFile(path);
+        uint8_t* px = (uint8_t*)malloc(t.RGBA8.size());
+        if (!px) throw std::runtime_error("out of memory");
+        std::memcpy(px, t.RGBA8.data(), t.RGBA8.size());
+        *width = t.Width; *height = t.Height; *rgba8 = px;
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return 1;
+    }
+}
+void pth_image_free(uint8_t* rgba8) { free(rgba8); }
+int pth_mesh_load_textures(pth_mesh* m, char* err, size_t errlen)
+{
+    try {
+        return (int)m->source->LoadTextures();
+    } catch (const std::exception& e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        return -1;
+    }
+}
 int pth_ppm_write(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, char* err, size_t errlen)
 {
     try {
