@@ -57,6 +57,9 @@ int pth_layer_read_image(pth_layer* l, float* rgba);
 int pth_layer_read_accum(pth_layer* l, float* rgba);
 int pth_layer_ray_count(pth_layer* l, uint64_t* rays);
 const char* pth_layer_last_error(pth_layer* l);
+/* transform editor (RayTracingLayer.cpp:569-604, "Automatically update AS" on): new WorldTransform of a submesh as a
+ * column-major mat4, acceleration structure recreated */
+int pth_layer_set_submesh_transform(pth_layer* l, uint32_t submesh, const float* column_major16);
 /* TextureCube{path = "...hdr"} (RayTracingLayer.cpp:50-54): load a Radiance image and make it the environment */
 int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face_size);
 /* m_DoPostProcessing / m_Exposure (RayTracingLayer.h:90-92, RayTracingLayer.cpp:522-524); on by default, 0.8 */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
 
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_default_params", "pt_scene_upload", "pt_build_accel",
-    "pt_update_materials", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
+    "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
     "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
     "pt_set_chains", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_device_image", "pt_device_accum",
@@ -76,6 +76,7 @@ def load_library():
     lib.pt_resolve.argtypes = [vp]
     lib.pt_read_primary_ids.argtypes = [vp, up]
     lib.pt_ray_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.pt_update_transforms.argtypes = [vp, fp, C.c_uint32, C.c_uint32, C.POINTER(AccelStats)]
     lib.pt_postprocess.argtypes = [vp, C.c_float]
     lib.pt_read_postprocessed.argtypes = [vp, C.POINTER(C.c_uint8)]
     lib.pt_env_from_equirect.argtypes = [vp, fp, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -198,6 +199,13 @@ class Backend:
         v = C.c_uint64()
         self._check(self.lib.pt_ray_count(self.h, C.byref(v)))
         return v.value
+
+    def update_transforms(self, xforms, flags=0):
+        """New per-submesh 3x4 object-to-world matrices (n, 12); rebuilds the hierarchy."""
+        x = np.ascontiguousarray(xforms, np.float32)
+        st = AccelStats()
+        self._check(self.lib.pt_update_transforms(self.h, _fp(x), x.size // 12, flags, C.byref(st)))
+        return st
 
     def postprocess(self, exposure=0.8):
         """Exposure, ACES fit, gamma 2.2 -> RGBA8 (H, W, 4) uint8 of the current image."""

@@ -350,6 +350,22 @@ int pt_update_materials(pt_ctx* ctx, const float* materials, uint32_t num_materi
     return PT_OK;
 }
 
+int pt_update_transforms(pt_ctx* ctx, const float* xforms, uint32_t num_submeshes, uint32_t build_flags, pt_accel_stats* stats)
+{
+    if (!ctx || !xforms) return PT_ERR_INVALID;
+    if (!ctx->scene_loaded || num_submeshes != ctx->num_submeshes)
+        return set_error(ctx, PT_ERR_INVALID, "pt_update_transforms: submesh count differs from the uploaded scene");
+    for (size_t k = 0; k < (size_t)num_submeshes * 12; k++)
+        if (!(xforms[k] == xforms[k]) || xforms[k] > 3e38f || xforms[k] < -3e38f) return set_error(ctx, PT_ERR_INVALID, "pt_update_transforms: matrix entry is not finite");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_SYNC(ctx);
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_xforms, xforms, (size_t)num_submeshes * 48, hipMemcpyHostToDevice, ctx->stream));
+    PT_SYNC(ctx);
+    int rc = build_accel(ctx, build_flags);
+    if (stats) *stats = ctx->accel_stats;
+    return rc;
+}
+
 int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
 {
     if (!ctx) return PT_ERR_INVALID;

@@ -7,7 +7,7 @@
 // and index offsets and material index (ClosestHit.glsl:147-156), and 88-byte material records
 // (ClosestHit.glsl:113-142).  Conventions where the engine is unknown: scene nodes are walked depth
 // first in file order; glTF defaults for missing factors (base colour 1, metallic 1, roughness 1,
-// emissive 0, emissive strength 1); KHR_materials_emissive_strength and KHR_materials_ior are read,
+// emissive 0, emissive strength 1); KHR_materials_emissive_strength, _ior, _transmission, _clearcoat, _sheen and _anisotropy are read,
 // ior defaults to 1.5 (the value Miss.glsl:28 uses), the other Disney parameters to 0; a missing
 // tangent becomes (1,0,0,1); texture indices are glTF image indices.
 #include "host.h"
@@ -223,6 +223,21 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
             if (const Json* ext = m.find("extensions")) {
                 if (const Json* es = ext->find("KHR_materials_emissive_strength")) d.EmissiveStrength = (float)es->get("emissiveStrength", 1.0);
                 if (const Json* io = ext->find("KHR_materials_ior")) d.ior = (float)io->get("ior", 1.5);
+                // the glTF material extensions that have a counterpart among the shader's Disney parameters
+                if (const Json* tr = ext->find("KHR_materials_transmission")) d.SpecTrans = (float)tr->get("transmissionFactor", 0.0);
+                if (const Json* cc = ext->find("KHR_materials_clearcoat")) {
+                    d.Clearcoat = (float)cc->get("clearcoatFactor", 0.0);
+                    d.ClearcoatRoughness = (float)cc->get("clearcoatRoughnessFactor", 0.0);
+                }
+                if (const Json* sh = ext->find("KHR_materials_sheen")) {
+                    float c[3] = {0.0f, 0.0f, 0.0f};
+                    if (const Json* sc = sh->find("sheenColorFactor")) for (int i = 0; i < 3; i++) c[i] = (float)sc->at(i).num;
+                    float hi = c[0] > c[1] ? (c[0] > c[2] ? c[0] : c[2]) : (c[1] > c[2] ? c[1] : c[2]);
+                    float lo = c[0] < c[1] ? (c[0] < c[2] ? c[0] : c[2]) : (c[1] < c[2] ? c[1] : c[2]);
+                    d.Sheen = hi;                                  // strength = brightest channel
+                    d.SheenTint = hi > 0.0f ? (hi - lo) / hi : 0.0f;   // 0 for a grey sheen colour, 1 for a saturated one
+                }
+                if (const Json* an = ext->find("KHR_materials_anisotropy")) d.Anisotropic = (float)an->get("anisotropyStrength", 0.0);
             }
             m_Materials.push_back(d);
         }

@@ -253,6 +253,17 @@ void AccelerationStructure::UpdateMaterialData()
     m_Device->Check(pt_update_materials(m_Device->Get(), reinterpret_cast<const float*>(mats.data()), (uint32_t)mats.size()), "pt_update_materials");
 }
 
+void AccelerationStructure::UpdateTransforms()
+{
+    std::vector<float> xforms;
+    for (const SubMesh& s : m_Spec.Mesh->GetSubMeshes()) {
+        Mat4 w = m_Spec.Transform * s.WorldTransform;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) xforms.push_back(w.at(r, c));
+    }
+    m_Device->Check(pt_update_transforms(m_Device->Get(), xforms.data(), (uint32_t)(xforms.size() / 12), PT_BUILD_DEFAULT, nullptr), "pt_update_transforms");
+}
+
 // ---- RayTracingLayer ------------------------------------------------------------------------------
 RayTracingLayer::RayTracingLayer(Ref<Device> device, Ref<Mesh> mesh, const Mat4& transform, const CameraSpecification& cameraSpec)
     : m_Device(std::move(device)), m_Mesh(std::move(mesh)), m_Transform(transform)
@@ -273,6 +284,12 @@ void RayTracingLayer::CreateAccelerationStructure()
     spec.Mesh = m_Mesh;
     spec.Transform = m_Transform;
     m_AccelerationStructure = CreateRef<AccelerationStructure>(m_Device, spec);
+}
+
+void RayTracingLayer::SetSubMeshTransform(uint32_t submesh, const Mat4& worldTransform)
+{
+    m_Mesh->GetSubMeshes().at(submesh).WorldTransform = worldTransform;
+    m_AccelerationStructure->UpdateTransforms();
 }
 
 void RayTracingLayer::SetViewportSize(uint32_t width, uint32_t height)

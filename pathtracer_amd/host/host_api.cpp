@@ -175,6 +175,14 @@ int pth_layer_read_accum(pth_layer* l, float* rgba)
 int pth_layer_ray_count(pth_layer* l, uint64_t* rays) { return guarded(l, [&] { *rays = l->layer->GetRayCount(); }); }
 const char* pth_layer_last_error(pth_layer* l) { return l ? l->error.c_str() : ""; }
 
+int pth_layer_set_submesh_transform(pth_layer* l, uint32_t submesh, const float* column_major16)
+{
+    return guarded(l, [&] {
+        ptamd::Mat4 m;
+        std::memcpy(&m, column_major16, sizeof(float) * 16);
+        l->layer->SetSubMeshTransform(submesh, m);
+    });
+}
 int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face_size)
 {
     return guarded(l, [&] { l->layer->SetRadianceMap(hdr_path, face_size); });

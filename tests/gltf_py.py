@@ -36,6 +36,15 @@ def _node_local(node):
     return m
 
 
+def _sheen(e):
+    """sheenColorFactor -> Disney sheen strength (brightest channel) and tint (saturation)."""
+    if not e:
+        return {}
+    c = np.asarray(e.get("sheenColorFactor", [0, 0, 0]), np.float32)
+    hi, lo = c.max(), c.min()
+    return {"sheen": hi, "sheen_tint": (hi - lo) / hi if hi > 0 else np.float32(0)}
+
+
 def load_gltf(path, layer_transform=None, use_textures=False):
     with open(path) as f:
         g = json.load(f)
@@ -75,7 +84,12 @@ def load_gltf(path, layer_transform=None, use_textures=False):
             roughness=pbr.get("roughnessFactor", 1.0), emissive=m.get("emissiveFactor", [0, 0, 0]),
             emissive_strength=ext.get("KHR_materials_emissive_strength", {}).get("emissiveStrength", 1.0),
             albedo_map=tex(pbr.get("baseColorTexture")), mr_map=tex(pbr.get("metallicRoughnessTexture")),
-            normal_map=tex(m.get("normalTexture")), ior=ext.get("KHR_materials_ior", {}).get("ior", 1.5)))
+            normal_map=tex(m.get("normalTexture")), ior=ext.get("KHR_materials_ior", {}).get("ior", 1.5),
+            spec_trans=ext.get("KHR_materials_transmission", {}).get("transmissionFactor", 0.0),
+            clearcoat=ext.get("KHR_materials_clearcoat", {}).get("clearcoatFactor", 0.0),
+            clearcoat_roughness=ext.get("KHR_materials_clearcoat", {}).get("clearcoatRoughnessFactor", 0.0),
+            anisotropic=ext.get("KHR_materials_anisotropy", {}).get("anisotropyStrength", 0.0),
+            **_sheen(ext.get("KHR_materials_sheen"))))
     default_mat = None
     verts, inds, subs, counts, xfs, names = [], [], [], [], [], []
     nv = ni = 0

@@ -544,3 +544,31 @@ def test_tracing_under_a_converted_environment(backend, cornell, cameras):
     assert np.array_equal(bits(backend.read_image()), bits(o.read_image()))
     with pytest.raises(BackendError):
         backend.env_preetham(3.0, 0.0, 0.0, face_size=0)
+
+
+def test_transform_edit_rebuilds_the_hierarchy(backend, cornell, cameras):
+    """RayTracingLayer.cpp:569-604: a submesh is moved / scaled and the acceleration structure recreated.  Same bits
+    as the oracle on the moved scene, and as a fresh upload of it."""
+    import copy
+    W, H = 160, 120
+    moved = copy.copy(cornell)
+    x = np.array(cornell.xforms, np.float32).reshape(-1, 12).copy()
+    k = len(x) - 1
+    m = x[k].reshape(3, 4)
+    m[:, 3] += np.array([0.03, 0.05, -0.02], np.float32)          # translate the last submesh
+    m[:, :3] *= np.float32(1.25)                                     # and scale it
+    x[0].reshape(3, 4)[0, 3] -= np.float32(0.01)
+    moved.xforms = x
+    o, rays = render_pair(backend, cornell, cameras["512x512"], W, H, (1, 2), spp_per_frame=1, max_bounces=4)
+    before = backend.read_image()
+    st = backend.update_transforms(x)
+    assert st.num_triangles == 63978 and st.num_nodes > 0
+    o2, rays2 = render_pair(backend, moved, cameras["512x512"], W, H, (1, 2), upload=False, spp_per_frame=1, max_bounces=4)
+    assert_same_frame(backend, o2, rays2)
+    assert not np.array_equal(backend.read_image(), before)
+    with pytest.raises(BackendError):
+        backend.update_transforms(x[:-1])
+    bad = x.copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(BackendError):
+        backend.update_transforms(bad)

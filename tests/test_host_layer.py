@@ -42,7 +42,11 @@ def write_gltf(tmp_path):
                                    {"attributes": {"POSITION": 0, "NORMAL": 1}, "indices": 2}]}],
         "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1], "metallicFactor": 0.25, "roughnessFactor": 0.5},
                        "emissiveFactor": [1, 0.5, 0.25],
-                       "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 3.0}, "KHR_materials_ior": {"ior": 1.33}}}],
+                       "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 3.0}, "KHR_materials_ior": {"ior": 1.33},
+                                      "KHR_materials_transmission": {"transmissionFactor": 0.75},
+                                      "KHR_materials_clearcoat": {"clearcoatFactor": 0.5, "clearcoatRoughnessFactor": 0.125},
+                                      "KHR_materials_sheen": {"sheenColorFactor": [0.5, 0.25, 0.125]},
+                                      "KHR_materials_anisotropy": {"anisotropyStrength": 0.375}}}],
         "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
                       {"bufferView": 1, "componentType": 5126, "count": 4, "type": "VEC3"},
                       {"bufferView": 2, "componentType": 5123, "count": 6, "type": "SCALAR"}],
@@ -231,6 +235,17 @@ def test_layer_post_processing_and_radiance_map(tmp_path):
     assert np.array_equal(layer.ReadPostProcessed(), oracle_lib.postprocess(layer.ReadImage(), 2.0))
     host.write_ppm(tmp_path / "frame.ppm", layer.ReadPostProcessed())
     assert (tmp_path / "frame.ppm").stat().st_size == len(b"P6\n40 24\n255\n") + 40 * 24 * 3
+    # moving a submesh recreates the acceleration structure and changes the picture; FrameIndex is left alone
+    before = layer.ReadImage()
+    frame = layer.FrameIndex
+    move = np.eye(4, dtype=np.float32)
+    move[:3, 3] = (0.5, 0.25, 0.0)
+    layer.SetSubMeshTransform(0, move)
+    assert layer.FrameIndex == frame
+    layer.SetAccumulate(False)
+    layer.OnUpdate(); layer.OnRender()
+    assert not np.array_equal(layer.ReadImage(), before)
+    layer.SetAccumulate(True)
     # a dark red sky: frame index restarts, and the sky colour shows in the pixels that miss everything
     sky = np.zeros((16, 32, 3))
     sky[..., 0] = 0.25
