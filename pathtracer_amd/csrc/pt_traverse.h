@@ -51,7 +51,7 @@ namespace ptd {
 #define PT_RAY_RESUME 2u
 #define PT_SUSPEND_WORDS (16 + 2 * PT_STACK_MAX)   // words of a suspended traversal: 16 of state, then the stack
 #define PT_CUR_NONE 0x7FFFFFFFu   // s.cur when the stack ran empty; node indices are below, leaf references above
-#define PT_OWNER_BYTES 256        // LDS bytes per wave for the triangle phase's work list
+#define PT_OWNER_BYTES (64 * PT_LEAF_MAX * 2)   // LDS bytes per wave for the triangle phase's work list (one uint16 per triangle)
 
 struct HitRec {
     float t, u, v;
@@ -319,23 +319,28 @@ PT_DEV bool wins_tie(const TriRec* __restrict__ tris, uint32_t cand, uint32_t be
     return cs < bs || (cs == bs && cp < bp);
 }
 
-// Triangle phase, run by the whole wave.  Every lane with a pending leaf owns 1..4 work items (its
+// Triangle phase, run by the whole wave.  Every lane with a pending leaf owns 1..PT_LEAF_MAX work items (its
 // triangles); the items are numbered through the wave and item j is tested by lane j % 64 in pass
 // j / 64, with the owner's ray fetched by lane permutes.  The owner then collects the distances of
 // its items, keeps the closest under the usual rules, and fetches that one's barycentric terms.
 // `owner` is this wave's PT_OWNER_BYTES-byte LDS work list.  Must be called in wave-uniform control flow.
 template <bool STATS>
-PT_DEV void leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, uint8_t* owner, uint32_t lane, uint32_t& stat_tris)
+PT_DEV void leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, uint16_t* owner, uint32_t lane, uint32_t& stat_tris)
 {
     const uint32_t first = s.pend & 0x0FFFFFFFu;
     const uint32_t cnt = has_pend ? ((s.pend >> 28) & 7u) + 1u : 0u;
-    // exclusive prefix sum of cnt (0..4) over the lanes, from three ballots
+    // exclusive prefix sum of cnt (0..PT_LEAF_MAX) over the lanes, from one ballot per bit
     unsigned long long b0 = __ballot((cnt & 1u) != 0), b1 = __ballot((cnt & 2u) != 0), b2 = __ballot((cnt & 4u) != 0);
-    const uint32_t off = lanes_below(b0) + 2u * lanes_below(b1) + 4u * lanes_below(b2);
-    const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+    uint32_t off = lanes_below(b0) + 2u * lanes_below(b1) + 4u * lanes_below(b2);
+    uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+    if (PT_LEAF_MAX >= 8u) {
+        unsigned long long b3 = __ballot((cnt & 8u) != 0);
+        off += 8u * lanes_below(b3);
+        total += 8u * (uint32_t)__popcll(b3);
+    }
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++)
-        if (k < cnt) owner[off + k] = (uint8_t)(lane | (k << 6));
+    for (uint32_t k = 0; k < PT_LEAF_MAX; k++)
+        if (k < cnt) owner[off + k] = (uint16_t)(lane | (k << 6));
     __syncthreads();
     const uint32_t kpack = (uint32_t)s.rp.kx | ((uint32_t)s.rp.ky << 2) | ((uint32_t)s.rp.kz << 4);
     for (uint32_t p0 = 0; p0 < total; p0 += 64u) {
@@ -363,7 +368,7 @@ PT_DEV void leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, 
         uint32_t win = lane;
         bool won = false;
 #pragma unroll
-        for (uint32_t kk = 0; kk < 4; kk++) {
+        for (uint32_t kk = 0; kk < PT_LEAF_MAX; kk++) {
             const uint32_t jj = off + kk;
             const float tk = lane_read(wt, jj & 63u);
             if (kk < cnt && (jj - p0) < 64u && tk < s.tmax) {
@@ -394,7 +399,7 @@ PT_DEV void finish_hit(Trav& s)
 // column of the wave's global spill area: entry k is ovf[k * 64]; owner is the wave's LDS work list.
 template <bool STATS, bool CUT, class Fetch, class Emit, class Suspend, class ResumeRecord>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
-                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint8_t* owner, Fetch fetch, Emit emit, Suspend suspend, ResumeRecord resume_record,
+                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint16_t* owner, Fetch fetch, Emit emit, Suspend suspend, ResumeRecord resume_record,
                        uint32_t& stat_nodes, uint32_t& stat_tris, WaveStats* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
