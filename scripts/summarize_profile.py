@@ -47,7 +47,11 @@ try:
     prod = agg.get("ptd::k_extend<false, true>")
     lines += ["", "bench.py inside this run: value %.1f %s, roofline.avg_launch_ms %.4f (HIP events, %d launches of the timing window), "
               "concurrency %.2f; rocprofv3 average of k_extend<false, true> over the whole run: %.4f ms"
-              % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], prod[1] / prod[0] * 1e-3 if prod else float("nan"))]
+              % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], prod[1] / prod[0] * 1e-3 if prod else float("nan")),
+              "", "Kernel tracing costs throughput here: the profiler's per-dispatch bookkeeping keeps fewer launches in flight at a time "
+              "(concurrency above, against about 5 without the profiler), so each launch shares the chip with fewer others and is shorter "
+              "than in an unprofiled run, where bench.py reports a higher value and a longer avg_launch_ms.  Compare the two numbers of this "
+              "run with each other."]
 except (OSError, IndexError, KeyError, ValueError):
     pass
 open(os.path.join(out_dir, tag + "_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
