@@ -16,6 +16,7 @@
 //   5. k_collapse     level by level: binary tree -> 8-wide nodes of 128 bytes with 8-bit quantised child
 //                     boxes, subtrees of <= 4 triangles become leaves, triangles are written out in leaf order
 #include "pt_context.h"
+#include "pt_traverse.h"
 #include "pt_math.h"
 #include <hipcub/hipcub.hpp>
 
@@ -219,7 +220,7 @@ __global__ void k_ploc_init(int n, const uint32_t* __restrict__ vals, const floa
     cid[j] = node;
 }
 
-// nearest neighbour (smallest surface area of the merged box) within PLOC_RADIUS places; ties -> lower index
+// nearest neighbour (smallest surface area of the merged box) within PLOC_RADIUS places
 __global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_nearest(int nc, const uint32_t* __restrict__ cid, const float4* __restrict__ b2lo,
                                                              const float4* __restrict__ b2hi, uint32_t* __restrict__ nearest)
 {
@@ -250,7 +251,10 @@ __global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_nearest(int nc, const uint3
         float ey = fmaxf(hy, shi[lj][1]) - fminf(ly, slo[lj][1]);
         float ez = fmaxf(hz, shi[lj][2]) - fminf(lz, slo[lj][2]);
         float a = ex * ey + ey * ez + ez * ex;
-        if (a < best) { best = a; bestj = j; }
+        // equal areas (duplicated geometry): prefer the partner with the smallest index xor.  The pair that is smallest in
+        // (area, xor) over the whole array then chooses each other, so every round merges, and a run of identical boxes
+        // pairs up (0,1)(2,3)... and halves per round instead of merging one pair at its end
+        if (a < best || (a == best && (i ^ j) < (i ^ bestj))) { best = a; bestj = j; }
     }
     nearest[i] = (uint32_t)bestj;
 }
@@ -607,8 +611,11 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
 
-    if (7u * depth + 1u > (uint32_t)(16 + 80))
-        return set_error(ctx, PT_ERR_BVH_DEPTH, "hierarchy has " + std::to_string(depth) + " levels; the traversal stack holds 96 entries (13 levels of 8-wide nodes)");
+    // a ray's stack holds at most 7 siblings per level and one entry more; the spill area is sized for that
+    if (7u * depth + 1u > (uint32_t)PT_STACK_MAX)
+        return set_error(ctx, PT_ERR_BVH_DEPTH, "hierarchy has " + std::to_string(depth) + " levels; the traversal stack is limited to " +
+                                                    std::to_string(PT_STACK_MAX) + " entries");
+    ctx->stack_entries = depth ? ((7u * depth + 1u + 7u) & ~7u) : 8u;
     ctx->accel_built = true;
     return PT_OK;
 }

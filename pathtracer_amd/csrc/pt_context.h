@@ -75,10 +75,11 @@ struct pt_ctx {
     uint32_t* d_counts = nullptr;   // per chain: rounds + 1 rows of queue sizes (one per shard of the chain), then as many rows of fetch cursors
     uint32_t counts_cap = 0;
     uint32_t defer_rounds = 2;      // rounds a path may fall behind because its ray was suspended at the tail of a launch (PT_DEFER; 0: off)
-    uint32_t* d_suspend = nullptr;  // suspended traversals, [chain][2][shard of the chain][slot][PT_SUSPEND_WORDS]
+    uint32_t* d_suspend = nullptr;  // suspended traversals, [chain][2][shard of the chain][slot][16 + 2 * stack_entries]
     size_t suspend_words = 0;
     uint2* d_spill = nullptr;       // traversal stack spill area, [chain][wave][entry][lane]
-    uint32_t spill_waves = 0;
+    size_t spill_entries = 0;       // allocated entries of d_spill
+    uint32_t stack_entries = 64;    // stack entries a ray can need in the built hierarchy (7 per level + 1), a multiple of 8
     unsigned long long* d_wave_trace = nullptr;   // PT_WAVE_TRACE=<file>: per-wave timeline of the extend launches
     size_t wave_trace_len = 0;
     uint32_t wave_trace_rounds = 0, wave_trace_waves = 0;

@@ -36,8 +36,7 @@ namespace ptd {
 
 #define PT_STACK_LDS 16     // ring in LDS, power of two
 #define PT_STACK_BLK 8      // entries moved per spill / restore
-#define PT_STACK_MAX 96     // host refuses hierarchies whose depth could need more entries than this
-#define PT_STACK_OVF PT_STACK_MAX   // entries per lane in the global spill area
+#define PT_STACK_MAX 1024   // host refuses hierarchies whose depth could need more entries than this (146 levels)
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 20   // free lanes that trigger a refill
 #endif
@@ -49,7 +48,7 @@ namespace ptd {
 #endif
 #define PT_RAY_CUTTABLE 1u // fetch flags: the ray may be suspended; the ray resumes a suspended traversal
 #define PT_RAY_RESUME 2u
-#define PT_SUSPEND_WORDS (16 + 2 * PT_STACK_MAX)   // words of a suspended traversal: 16 of state, then the stack
+#define PT_SUSPEND_STATE_WORDS 16   // a suspended traversal is 16 words of state followed by the stack (2 words per entry)
 #define PT_CUR_NONE 0x7FFFFFFFu   // s.cur when the stack ran empty; node indices are below, leaf references above
 #define PT_OWNER_BYTES (64 * PT_LEAF_MAX * 2)   // LDS bytes per wave for the triangle phase's work list (one uint16 per triangle)
 
@@ -286,7 +285,7 @@ PT_DEV void trav_save(const Trav& s, uint32_t* rec, const uint2* lds_stack, int 
 {
     rec[0] = f2u(s.best.t); rec[1] = s.best.tri; rec[2] = f2u(s.bV); rec[3] = f2u(s.bW); rec[4] = f2u(s.bdet);
     rec[5] = s.cur; rec[6] = f2u(s.cur_key); rec[7] = s.pend; rec[8] = (uint32_t)s.sp;
-    uint2* st = reinterpret_cast<uint2*>(rec + 16);
+    uint2* st = reinterpret_cast<uint2*>(rec + PT_SUSPEND_STATE_WORDS);
     for (int k = 0; k < s.base; k++) st[k] = ovf[k * 64];
     for (int k = s.base; k < s.sp; k++) st[k] = lds_stack[(k & (PT_STACK_LDS - 1)) * stride];
 }
@@ -298,7 +297,7 @@ PT_DEV void trav_restore(Trav& s, const uint32_t* rec, uint2* lds_stack, int str
     s.cur = rec[5]; s.cur_key = u2f(rec[6]); s.pend = rec[7]; s.sp = (int)rec[8];
     // the top of the stack goes to the LDS ring, whole blocks below it to the spill column
     s.base = s.sp > PT_STACK_LDS ? ((s.sp - PT_STACK_BLK - 1) & ~(PT_STACK_BLK - 1)) : 0;
-    const uint2* st = reinterpret_cast<const uint2*>(rec + 16);
+    const uint2* st = reinterpret_cast<const uint2*>(rec + PT_SUSPEND_STATE_WORDS);
     for (int k = 0; k < s.base; k++) ovf[k * 64] = st[k];
     for (int k = s.base; k < s.sp; k++) lds_stack[(k & (PT_STACK_LDS - 1)) * stride] = st[k];
 }

@@ -153,7 +153,9 @@ struct ExtendArgs {
     uint32_t shard0, nshards, shard_cap;
     uint32_t max_lag;           // a path may fall this many rounds behind
     uint32_t susp_cap;          // suspended-traversal records per shard
-    const uint32_t* susp_in;    // records of the rays suspended by the previous round, [shard of the chain][slot][PT_SUSPEND_WORDS]
+    uint32_t susp_words;        // words per record: PT_SUSPEND_STATE_WORDS + 2 * stack_entries
+    uint32_t stack_entries;     // entries of a lane's column in the spill area = the deepest stack the hierarchy can cause
+    const uint32_t* susp_in;    // records of the rays suspended by the previous round, [shard of the chain][slot][susp_words]
     uint32_t* susp_out;         // records for the next round
     const float4* rayO; const float4* rayD;
     float4* next_rayO; float4* next_rayD;
@@ -197,11 +199,11 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
         a.next_rayO[base + slot] = ro;
         a.next_rayD[base + slot] = make_float4(rd.x, rd.y, rd.z, u2f(((f2u(rd.w) & RAY_LAG_MASK) + 1u) | RAY_RESUMES));
         a.hits[base + i] = make_float4(0.0f, 0.0f, 0.0f, u2f(DEFERRED));
-        trav_save(s, a.susp_out + ((size_t)ls * a.susp_cap + slot) * PT_SUSPEND_WORDS, lds_stack, stride, ovf);
+        trav_save(s, a.susp_out + ((size_t)ls * a.susp_cap + slot) * a.susp_words, lds_stack, stride, ovf);
     };
-    auto resume_record = [&](uint32_t i) { return a.susp_in + ((size_t)ls * a.susp_cap + i) * PT_SUSPEND_WORDS; };
+    auto resume_record = [&](uint32_t i) { return a.susp_in + ((size_t)ls * a.susp_cap + i) * a.susp_words; };
     trace_wave<STATS, CUT>(sc.nodes, sc.tris, sc.num_tris, n, &a.cursors[ls], stack + threadIdx.x, EXT_BLOCK,
-                           a.spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner, fetch, emit, suspend, resume_record, sn, st, STATS ? &ws : nullptr);
+                           a.spill + (size_t)blockIdx.x * (a.stack_entries * 64) + threadIdx.x, owner, fetch, emit, suspend, resume_record, sn, st, STATS ? &ws : nullptr);
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
@@ -484,14 +486,15 @@ __global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __
     reinterpret_cast<float4*>(image)[g] = out;
 }
 
-// global spill area of the traversal stacks: one [PT_STACK_OVF][64] block of entries per wave
+// global spill area of the traversal stacks: one [stack_entries][64] block of entries per wave
 static int ensure_spill(pt_ctx* ctx, uint32_t waves)
 {
-    if (waves <= ctx->spill_waves) return PT_OK;
+    size_t need = (size_t)waves * ctx->stack_entries * 64;
+    if (need <= ctx->spill_entries) return PT_OK;
     PT_SYNC(ctx);
-    if (ctx->d_spill) { (void)hipFree(ctx->d_spill); ctx->d_spill = nullptr; ctx->spill_waves = 0; }
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_spill, (size_t)waves * PT_STACK_OVF * 64 * sizeof(uint2)));
-    ctx->spill_waves = waves;
+    if (ctx->d_spill) { (void)hipFree(ctx->d_spill); ctx->d_spill = nullptr; ctx->spill_entries = 0; }
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_spill, need * sizeof(uint2)));
+    ctx->spill_entries = need;
     return PT_OK;
 }
 
@@ -586,8 +589,9 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     // records of suspended traversals: per chain two pools (the round's own and the next round's), per shard one
     // record for each ray the shard's waves can suspend in a launch
     const uint32_t susp_cap = (ext_blocks / spc) * PT_CUT_LANES;
+    const uint32_t susp_words = PT_SUSPEND_STATE_WORDS + 2u * ctx->stack_entries;
     {
-        size_t need = (size_t)chains * 2 * spc * susp_cap * PT_SUSPEND_WORDS;
+        size_t need = (size_t)chains * 2 * spc * susp_cap * susp_words;
         if (ctx->defer_rounds && need > ctx->suspend_words) {
             PT_SYNC(ctx);
             if (ctx->d_suspend) (void)hipFree(ctx->d_suspend);
@@ -637,7 +641,7 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         q.shard_cap = ctx->shard_cap;
         q.primary = ctx->d_primary;
         q.image = ctx->d_image; q.accum = ctx->d_accum;
-        uint2* spill = ctx->d_spill + (size_t)c * ext_blocks * (PT_STACK_OVF * 64);
+        uint2* spill = ctx->d_spill + (size_t)c * ext_blocks * (ctx->stack_entries * 64);
 
         PT_HIP(ctx, mark());
         {
@@ -656,8 +660,10 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
             ea.next_counts = (ctx->defer_rounds && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
             ea.max_lag = ctx->defer_rounds;
             ea.susp_cap = susp_cap;
-            ea.susp_in = ctx->d_suspend + ((size_t)(c * 2 + in) * spc) * susp_cap * PT_SUSPEND_WORDS;
-            ea.susp_out = ctx->d_suspend + ((size_t)(c * 2 + out) * spc) * susp_cap * PT_SUSPEND_WORDS;
+            ea.susp_words = susp_words;
+            ea.stack_entries = ctx->stack_entries;
+            ea.susp_in = ctx->d_suspend + ((size_t)(c * 2 + in) * spc) * susp_cap * susp_words;
+            ea.susp_out = ctx->d_suspend + ((size_t)(c * 2 + out) * spc) * susp_cap * susp_words;
             ea.deferred = deferred;
             ea.shard0 = q.shard0; ea.nshards = spc; ea.shard_cap = ctx->shard_cap;
             ea.rayO = ctx->d_rayO[in]; ea.rayD = ctx->d_rayD[in];
@@ -698,14 +704,14 @@ int launch_resolve(pt_ctx* ctx)
 
 // ---- inspection hooks --------------------------------------------------------------------------
 __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uint32_t n, uint32_t* cursor, const float4* __restrict__ rays,
-                                                                uint32_t* __restrict__ out, uint2* spill, unsigned long long* stats)
+                                                                uint32_t* __restrict__ out, uint2* spill, uint32_t stack_entries, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     __shared__ uint16_t owner[PT_OWNER_BYTES / 2];
     uint32_t sn = 0, st = 0;
     trace_wave<true, false>(
         sc.nodes, sc.tris, sc.num_tris, n, cursor, stack + threadIdx.x, EXT_BLOCK,
-        spill + (size_t)blockIdx.x * (PT_STACK_OVF * 64) + threadIdx.x, owner,
+        spill + (size_t)blockIdx.x * (stack_entries * 64) + threadIdx.x, owner,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rays[2 * i], rd = rays[2 * i + 1];
             o = V3(ro.x, ro.y, ro.z);
@@ -799,7 +805,7 @@ int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, 
         int rc = ensure_spill(ctx, blocks);
         if (rc) return rc;
     }
-    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(ctx->d_stats + 2), d_rays.p, d_out.p, ctx->d_spill, ctx->d_stats);
+    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(ctx->d_stats + 2), d_rays.p, d_out.p, ctx->d_spill, ctx->stack_entries, ctx->d_stats);
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipMemcpyAsync(hits, d_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, st));
     unsigned long long hs[2] = {0, 0};

@@ -572,3 +572,45 @@ def test_transform_edit_rebuilds_the_hierarchy(backend, cornell, cameras):
     bad[0, 0] = np.nan
     with pytest.raises(BackendError):
         backend.update_transforms(bad)
+
+
+def _soup(tris):
+    """SceneData of independent triangles (n, 3, 3), one submesh, identity transform."""
+    n = len(tris)
+    v = np.zeros((3 * n, 12), np.float32)
+    v[:, 0:3] = np.asarray(tris, np.float32).reshape(-1, 3)
+    v[:, 5:8] = (0, 0, 1)
+    ident = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], np.float32)
+    return SceneData(v, np.arange(3 * n, dtype=np.uint32), [(0, 0, 0, 0)], [3 * n], ident, [make_material()])
+
+
+@pytest.mark.parametrize("kind", ["duplicates", "line", "scales", "slivers"])
+def test_degenerate_distributions_build_and_trace(backend, kind):
+    """Inputs that make spatial orders degenerate: the build must neither fail nor produce a hierarchy that is too
+    deep for the traversal stack, and traversal must still equal the brute-force loop."""
+    rng = np.random.default_rng(11)
+    n = 60000
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    if kind == "duplicates":                       # the same triangle many times, plus a few others
+        tris = np.repeat(base[None], n, 0)
+        tris[: n // 100] += rng.uniform(-3, 3, (n // 100, 1, 3)).astype(np.float32)
+    elif kind == "line":                           # a one-dimensional distribution
+        tris = base[None] * 1e-3 + np.stack([np.arange(n) * 2e-3, np.zeros(n), np.zeros(n)], -1)[:, None, :].astype(np.float32)
+    elif kind == "scales":                         # sizes over six orders of magnitude
+        s = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n)).astype(np.float32)
+        tris = base[None] * s[:, None, None] + rng.uniform(-50, 50, (n, 1, 3)).astype(np.float32)
+    else:                                          # long thin triangles crossing the whole scene
+        a = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32) * 20
+        tris = np.stack([a, a + d, a + d + rng.normal(size=(n, 3)).astype(np.float32) * 1e-2], 1)
+    sc = _soup(tris.astype(np.float32))
+    backend.scene_upload(sc)
+    st = backend.build_accel()
+    assert st.num_triangles == n and 7 * st.max_depth + 1 <= 1024
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    rays = random_rays(rng, 3000, lo - 1, hi + 1)
+    got, _ = backend.debug_intersect(rays)
+    o = oracle_lib.Oracle(sc)
+    want = o.intersect(rays, use_bvh=False)
+    assert np.array_equal(got, want)
+    assert (got[:, 3] != M32).sum() > 10 or kind == "line"
