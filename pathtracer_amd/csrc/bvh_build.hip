@@ -77,6 +77,13 @@ __global__ void k_world_tris(uint32_t n, uint32_t ns, const uint32_t* __restrict
         lo[0] = fminf(fminf(w[0].x, w[1].x), w[2].x); hi[0] = fmaxf(fmaxf(w[0].x, w[1].x), w[2].x);
         lo[1] = fminf(fminf(w[0].y, w[1].y), w[2].y); hi[1] = fmaxf(fmaxf(w[0].y, w[1].y), w[2].y);
         lo[2] = fminf(fminf(w[0].z, w[1].z), w[2].z); hi[2] = fmaxf(fmaxf(w[0].z, w[1].z), w[2].z);
+        // a triangle with a NaN or infinite coordinate can never be hit (every test on it compares false): it gets the
+        // empty box, the identity of box union, so that it neither moves the scene bounds nor attracts a ray
+        float sum = 0.0f;
+        for (int k = 0; k < 3; k++) sum += (w[k].x - w[k].x) + (w[k].y - w[k].y) + (w[k].z - w[k].z);   // 0 iff all nine are finite
+        if (!(sum == 0.0f)) {
+            for (int k = 0; k < 3; k++) { lo[k] = 3.4028235e38f; hi[k] = -3.4028235e38f; }
+        }
         tlo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         thi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_nearest(int nc, const uint3
         // equal areas (duplicated geometry): prefer the partner with the smallest index xor.  The pair that is smallest in
         // (area, xor) over the whole array then chooses each other, so every round merges, and a run of identical boxes
         // pairs up (0,1)(2,3)... and halves per round instead of merging one pair at its end
-        if (a < best || (a == best && (i ^ j) < (i ^ bestj))) { best = a; bestj = j; }
+        if (bestj < 0 || a < best || (a == best && (i ^ j) < (i ^ bestj))) { best = a; bestj = j; }
     }
     nearest[i] = (uint32_t)bestj;
 }
@@ -316,7 +323,7 @@ __device__ __forceinline__ uint32_t grid_exponent(float extent)
     uint32_t bits = __float_as_uint(f);
     uint32_t e = (bits >> 23) & 255u;
     if (bits & 0x007fffffu) e++;                   // not an exact power of two: round the step up
-    return e > 254u ? 254u : e;
+    return e > 253u ? 253u : e;                    // 255 steps of 2^126 span every finite extent; the inverse step stays normal
 }
 
 // one thread per frontier item: builds one Node8 and queues its internal children
@@ -383,10 +390,11 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
             uint32_t cnt = __float_as_uint(lo.w);
             float l3[3] = {lo.x - pad, lo.y - pad, lo.z - pad}, h3[3] = {hi.x + pad, hi.y + pad, hi.z + pad};
             for (int a = 0; a < 3; a++) {
-                float ql = floorf((l3[a] - lo3[a]) * inv3[a]);
-                float qh = ceilf((h3[a] - lo3[a]) * inv3[a]);
-                qlo[a] = (uint32_t)fminf(fmaxf(ql, 0.0f), 255.0f);
-                qhi[a] = (uint32_t)fminf(fmaxf(qh, 0.0f), 255.0f);
+                // in double: the difference of two large floats must not overflow or round the wrong way
+                double ql = floor(((double)l3[a] - (double)lo3[a]) * (double)inv3[a]);
+                double qh = ceil(((double)h3[a] - (double)lo3[a]) * (double)inv3[a]);
+                qlo[a] = (uint32_t)fmin(fmax(ql, 0.0), 255.0);
+                qhi[a] = (uint32_t)fmin(fmax(qh, 0.0), 255.0);
             }
             if (cnt <= PT_LEAF_MAX) {
                 nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
@@ -513,6 +521,20 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     k_init_bounds<<<1, 64, 0, st>>>(bounds.p);
     k_world_tris<<<G, B, 0, st>>>(n, ctx->num_submeshes, ctx->d_sub_tri_offset, ctx->d_submeshes, ctx->d_xforms,
                                   ctx->d_indices, ctx->d_vertices, tris_tmp.p, tlo.p, thi.p, bounds.p);
+    // scene bounds over the triangles that can be hit
+    int hb[6];
+    PT_HIP(ctx, hipMemcpyAsync(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    auto o2f = [](int i) { uint32_t u = (uint32_t)(i >= 0 ? i : i ^ 0x7fffffff); float f; memcpy(&f, &u, 4); return f; };
+    float lo[3] = {o2f(hb[0]), o2f(hb[1]), o2f(hb[2])}, hi[3] = {o2f(hb[3]), o2f(hb[4]), o2f(hb[5])};
+    if (!(lo[0] <= hi[0])) {                      // no triangle has finite coordinates
+        for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0.0f;
+        PT_HIP(ctx, hipMemsetAsync(bounds.p, 0, 6 * sizeof(int), st));
+    }
+    float mc = 0.0f;
+    for (int k = 0; k < 3; k++) mc = fmaxf(mc, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+    // the quantised boxes and the slab test multiply extents by 1/direction: keep well inside the float range
+    if (!(mc <= 1.0e18f)) return set_error(ctx, PT_ERR_INVALID, "scene coordinates beyond +-1e18 are not supported");
     k_morton<<<G, B, 0, st>>>(n, tlo.p, thi.p, bounds.p, keys.p, vals.p);
     size_t tmp_bytes = 0;
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
@@ -560,14 +582,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     }
 
     // padding of every child box: covers the rounding of the slab test and of the triangle test's t
-    int hb[6];
-    PT_HIP(ctx, hipMemcpyAsync(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost, st));
-    PT_HIP(ctx, hipStreamSynchronize(st));
-    auto o2f = [](int i) { uint32_t u = (uint32_t)(i >= 0 ? i : i ^ 0x7fffffff); float f; memcpy(&f, &u, 4); return f; };
-    float lo[3] = {o2f(hb[0]), o2f(hb[1]), o2f(hb[2])}, hi[3] = {o2f(hb[3]), o2f(hb[4]), o2f(hb[5])};
     float diag = sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-    float mc = 0.0f;
-    for (int k = 0; k < 3; k++) mc = fmaxf(mc, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
     float pad = fmaxf(diag, mc) * (1.0f / 262144.0f);
     if (!(pad == pad) || pad > 3.0e38f) return set_error(ctx, PT_ERR_INVALID, "scene bounds are not finite");
 

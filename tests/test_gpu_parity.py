@@ -584,7 +584,7 @@ def _soup(tris):
     return SceneData(v, np.arange(3 * n, dtype=np.uint32), [(0, 0, 0, 0)], [3 * n], ident, [make_material()])
 
 
-@pytest.mark.parametrize("kind", ["duplicates", "line", "scales", "slivers"])
+@pytest.mark.parametrize("kind", ["duplicates", "line", "scales", "slivers", "zero_area", "huge", "nonfinite"])
 def test_degenerate_distributions_build_and_trace(backend, kind):
     """Inputs that make spatial orders degenerate: the build must neither fail nor produce a hierarchy that is too
     deep for the traversal stack, and traversal must still equal the brute-force loop."""
@@ -599,15 +599,33 @@ def test_degenerate_distributions_build_and_trace(backend, kind):
     elif kind == "scales":                         # sizes over six orders of magnitude
         s = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n)).astype(np.float32)
         tris = base[None] * s[:, None, None] + rng.uniform(-50, 50, (n, 1, 3)).astype(np.float32)
+    elif kind == "zero_area":                      # points and segments among ordinary triangles
+        tris = base[None] * 0.1 + rng.uniform(-5, 5, (n, 1, 3)).astype(np.float32)
+        tris[::3, 1] = tris[::3, 0]
+        tris[::7, 2] = tris[::7, 0]
+    elif kind == "huge":                           # coordinates far beyond what squares without overflow
+        tris = (base[None] + rng.uniform(-5, 5, (n, 1, 3))).astype(np.float32)
+        tris[:50] *= np.float32(1e18)
+        tris[50:100] *= np.float32(3e37)
+    elif kind == "nonfinite":                      # a renderer gets handed these; they must hit nothing and break nothing
+        tris = (base[None] + rng.uniform(-5, 5, (n, 1, 3))).astype(np.float32)
+        tris[:200, 0, 0] = np.nan
+        tris[200:400, 1, 2] = np.inf
+        tris[400:600, 2, 1] = -np.inf
     else:                                          # long thin triangles crossing the whole scene
         a = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
         d = rng.normal(size=(n, 3)).astype(np.float32) * 20
         tris = np.stack([a, a + d, a + d + rng.normal(size=(n, 3)).astype(np.float32) * 1e-2], 1)
     sc = _soup(tris.astype(np.float32))
     backend.scene_upload(sc)
+    if kind == "huge":                             # refused with a message rather than traced wrongly
+        with pytest.raises(BackendError, match="1e18"):
+            backend.build_accel()
+        return
     st = backend.build_accel()
     assert st.num_triangles == n and 7 * st.max_depth + 1 <= 1024
-    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    finite = tris.reshape(-1, 3)[np.isfinite(tris.reshape(-1, 3)).all(1) & (np.abs(tris.reshape(-1, 3)) < 1e6).all(1)]
+    lo, hi = finite.min(0), finite.max(0)
     rays = random_rays(rng, 3000, lo - 1, hi + 1)
     got, _ = backend.debug_intersect(rays)
     o = oracle_lib.Oracle(sc)
