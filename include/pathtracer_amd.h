@@ -123,8 +123,12 @@ int pt_bind_images(pt_ctx* ctx, void* device_image, void* device_accum);
 int pt_set_camera(pt_ctx* ctx, const float* five_mat4);
 int pt_set_params(pt_ctx* ctx, const pt_params* params);
 /* vkCmdTraceRaysKHR(width, height, 1) with SceneBuffer.FrameIndex = frame_index, binding 7
- * (RayTracingLayer.cpp:274-283, RayGen.glsl:312-373).  Asynchronous on the context's
- * stream.  The caller sequences frame_index (1-based; 1 clears the accumulation image). */
+ * (RayTracingLayer.cpp:274-283, RayGen.glsl:312-373).  Asynchronous: the frame takes the camera
+ * and parameters in force at the call and is queued; up to pt_set_batch consecutive frames are
+ * launched together, when the batch is full or at the next call that reads, waits for or changes
+ * what the queued frames use (every other entry point except pt_set_camera).  Frames are added to
+ * the accumulation image in call order whatever the batching, so images do not depend on it.
+ * The caller sequences frame_index (1-based; 1 clears the accumulation image). */
 int pt_trace(pt_ctx* ctx, uint32_t frame_index);
 /* waits for the stream (the reference's Submit + FlushCommandBuffer, RayTracingLayer.cpp:317,424) */
 int pt_sync(pt_ctx* ctx);
@@ -166,6 +170,12 @@ int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
  * environment (HIP reads it when its runtime starts).  No counterpart in the reference, whose
  * scheduling is the Vulkan driver's. */
 int pt_set_chains(pt_ctx* ctx, uint32_t chains);
+/* Up to `frames` (1..4) consecutive pt_trace calls share their kernel launches: the paths of all
+ * of them fill one set of ray queues, so a launch has that many times the rays to hide its tail
+ * behind.  1 launches every frame at its pt_trace call (lowest latency for an interactive viewer
+ * that displays every frame); the default, 4, is the throughput setting for progressive
+ * accumulation.  No counterpart in the reference, which records one vkCmdTraceRaysKHR per frame. */
+int pt_set_batch(pt_ctx* ctx, uint32_t frames);
 /* mode 1: every kernel launch of later pt_trace calls is bracketed by HIP events on the stream
  * it runs on; pt_last_trace_timing waits for the frames issued so far and reports their
  * per-kernel time, summed since its previous call (or since the mode was set).

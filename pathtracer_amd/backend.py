@@ -18,7 +18,7 @@ EXPORTS = [
     "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
     "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
-    "pt_set_chains", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_device_image", "pt_device_accum",
+    "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_device_image", "pt_device_accum",
     "pt_debug_intersect", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
 ]
 
@@ -83,6 +83,7 @@ def load_library():
     lib.pt_env_preetham.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_uint32]
     lib.pt_read_env.argtypes = [vp, fp, up]
     lib.pt_set_chains.argtypes = [vp, C.c_uint32]
+    lib.pt_set_batch.argtypes = [vp, C.c_uint32]
     lib.pt_set_profiling.argtypes = [vp, C.c_int]
     lib.pt_last_trace_timing.argtypes = [vp, C.POINTER(TraceTiming)]
     for name in ("pt_stream", "pt_device_image", "pt_device_accum", "pt_device_postprocessed"):
@@ -233,6 +234,10 @@ class Backend:
     def set_chains(self, chains):
         """Number of independent pipelines (1, 2, 4 or 8) a frame is split into; images do not depend on it."""
         self._check(self.lib.pt_set_chains(self.h, int(chains)))
+
+    def set_batch(self, frames):
+        """Consecutive trace() calls (1..4) that share their kernel launches; images do not depend on it."""
+        self._check(self.lib.pt_set_batch(self.h, int(frames)))
 
     def set_profiling(self, mode):
         """0 off, 1 per-kernel HIP-event timing, 2 timing + traversal node/triangle counters."""

@@ -41,7 +41,7 @@ static void free_images(pt_ctx* c)
 {
     (void)dev_free(c->d_image_own); (void)dev_free(c->d_accum_own); (void)dev_free(c->d_primary); (void)dev_free(c->d_post);
     (void)dev_free(c->d_rayO[0]); (void)dev_free(c->d_rayO[1]); (void)dev_free(c->d_rayD[0]); (void)dev_free(c->d_rayD[1]);
-    (void)dev_free(c->d_hits); (void)dev_free(c->d_stA); (void)dev_free(c->d_stB); (void)dev_free(c->d_stC);
+    (void)dev_free(c->d_hits); (void)dev_free(c->d_stA); (void)dev_free(c->d_stB); (void)dev_free(c->d_stC); (void)dev_free(c->d_partial);
     c->d_image = c->d_accum = nullptr;
     c->width = c->height = 0;
 }
@@ -97,6 +97,10 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
 // collects every frame still in flight and closes the timing window: totals into ctx->timing
 static int finish_timing(pt_ctx* ctx)
 {
+    if (!ctx->pending.empty()) {
+        int rc = launch_trace(ctx);
+        if (rc) return rc;
+    }
     if (!ctx->window_open) return PT_OK;
     for (uint32_t k = 0; k < PT_PROF_SLOTS; k++) {
         int rc = collect_slot(ctx, ctx->prof_slot[(ctx->prof_next + k) % PT_PROF_SLOTS]);
@@ -136,6 +140,10 @@ static int finish_timing(pt_ctx* ctx)
 
 int sync_streams(pt_ctx* ctx)
 {
+    if (!ctx->pending.empty()) {
+        int rc = launch_trace(ctx);
+        if (rc) return rc;
+    }
     for (uint32_t c = PT_MAX_CHAINS; c-- > 0;)
         if (ctx->chain_stream[c]) PT_HIP(ctx, hipStreamSynchronize(ctx->chain_stream[c]));
     ctx->join_pending = false;
@@ -144,6 +152,10 @@ int sync_streams(pt_ctx* ctx)
 
 int join_chains(pt_ctx* ctx)
 {
+    if (!ctx->pending.empty()) {
+        int rc = launch_trace(ctx);
+        if (rc) return rc;
+    }
     if (!ctx->join_pending) return PT_OK;
     for (uint32_t c = 1; c < ctx->chains; c++) {
         PT_HIP(ctx, hipEventRecord(ctx->chain_done[c], ctx->chain_stream[c]));
@@ -194,6 +206,8 @@ int pt_create(int device_ordinal, pt_ctx** out)
         if (c >= 1 && c <= PT_MAX_CHAINS && PT_SHARDS % c == 0) ctx->chains = c;
     }
     if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
+    if (const char* e = getenv("PT_BATCH")) { int v = atoi(e); ctx->batch = v < 1 ? 1u : (v > PT_MAX_BATCH ? (uint32_t)PT_MAX_BATCH : (uint32_t)v); }
+    if (es == hipSuccess) es = hipMalloc((void**)&ctx->d_views, sizeof(FrameView) * PT_MAX_BATCH * PT_MAX_CHAINS);
     hipError_t e1 = hipMalloc((void**)&ctx->d_total_rays, 8);
     hipError_t e2 = hipMalloc((void**)&ctx->d_stats, 128);
     if (es != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) { pt_destroy(ctx); return set_error(nullptr, PT_ERR_HIP, "context allocation failed"); }
@@ -212,6 +226,7 @@ void pt_destroy(pt_ctx* ctx)
     free_images(ctx);
     (void)dev_free(ctx->d_counts);
     (void)dev_free(ctx->d_spill);
+    (void)dev_free(ctx->d_views);
     (void)dev_free(ctx->d_suspend);
     (void)dev_free(ctx->d_wave_trace);
     (void)dev_free(ctx->d_total_rays);
@@ -370,13 +385,13 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (width == 0 || height == 0) return set_error(ctx, PT_ERR_INVALID, "pt_resize: empty image");
-    if ((uint64_t)width * height > (1ull << 28)) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_resize: more than 2^28 pixels");
+    if ((uint64_t)width * height > (1ull << 28) / PT_MAX_BATCH) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_resize: more than 2^26 pixels");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_SYNC(ctx);
     free_images(ctx);
     size_t n = (size_t)width * height;
     size_t tiles = (size_t)((width + 7) / 8) * ((height + 7) / 8);
-    ctx->shard_cap = (uint32_t)((tiles + PT_SHARDS - 1) / PT_SHARDS) * 64u;
+    ctx->shard_cap = (uint32_t)((tiles + PT_SHARDS - 1) / PT_SHARDS) * 64u * PT_MAX_BATCH;
     size_t slots = (size_t)ctx->shard_cap * PT_SHARDS;
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_image_own, n * 16));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_accum_own, n * 16));
@@ -386,9 +401,10 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_rayD[i], slots * 16));
     }
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_hits, slots * 16));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stA, n * 16));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stB, n * 16));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stC, n * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stA, n * PT_MAX_BATCH * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stB, n * PT_MAX_BATCH * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stC, n * PT_MAX_BATCH * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_partial, n * PT_MAX_BATCH * 16));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_image_own, 0, n * 16, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_accum_own, 0, n * 16, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, n * 8, ctx->stream));
@@ -424,6 +440,12 @@ int pt_set_params(pt_ctx* ctx, const pt_params* p)
     if (p->spp_per_frame == 0 || p->max_bounces == 0) return set_error(ctx, PT_ERR_INVALID, "spp_per_frame and max_bounces must be >= 1");
     if (p->spp_per_frame > 0xFFFFu || p->max_bounces > 0xFFFFu || (uint64_t)p->spp_per_frame * p->max_bounces > 65536ull)
         return set_error(ctx, PT_ERR_TOO_LARGE, "spp_per_frame * max_bounces must not exceed 65536");
+    if (!ctx->pending.empty()) {      // frames already handed in keep the parameters they were traced with
+        int rc = launch_trace(ctx);
+        if (rc) return rc;
+    }
+    // the chains' shares of the queue counters are laid out by the number of rounds: frames still running keep theirs
+    if ((uint64_t)p->spp_per_frame * p->max_bounces != (uint64_t)ctx->params.spp_per_frame * ctx->params.max_bounces) PT_SYNC(ctx);
     ctx->params = *p;
     return PT_OK;
 }
@@ -440,6 +462,18 @@ int pt_set_chains(pt_ctx* ctx, uint32_t chains)
     }
     ctx->chains = chains;
     ctx->main_dirty = true;
+    return PT_OK;
+}
+
+int pt_set_batch(pt_ctx* ctx, uint32_t frames)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (frames < 1 || frames > PT_MAX_BATCH) return set_error(ctx, PT_ERR_INVALID, "pt_set_batch: frames must be 1..4");
+    if (!ctx->pending.empty()) {
+        int rc = launch_trace(ctx);
+        if (rc) return rc;
+    }
+    ctx->batch = frames;
     return PT_OK;
 }
 
@@ -468,7 +502,13 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, pt_chain_words(rounds, PT_SHARDS) * sizeof(uint32_t)));
         ctx->counts_cap = rounds + 1;
     }
-    return launch_trace(ctx, frame_index);
+    FrameView v;
+    v.frame = frame_index;
+    memcpy(v.inv_view, ctx->camera + 48, 64);
+    memcpy(v.inv_proj, ctx->camera + 64, 64);
+    ctx->pending.push_back(v);
+    if (ctx->pending.size() >= ctx->batch) return launch_trace(ctx);
+    return PT_OK;
 }
 
 int pt_sync(pt_ctx* ctx)

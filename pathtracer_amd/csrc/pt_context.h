@@ -71,6 +71,12 @@ struct pt_ctx {
     float4* d_stA = nullptr;
     float4* d_stB = nullptr;
     float4* d_stC = nullptr;
+    float4* d_partial = nullptr;    // finished colour per (frame slot, pixel)
+    ptd::FrameView* d_views = nullptr;   // per chain PT_MAX_BATCH frame views, written on the chain's stream
+    // frames handed to pt_trace and not launched yet: up to `batch` of them share their launches (more rays per launch).
+    // Everything that synchronises, reads or changes what the kernels read launches them first.
+    std::vector<ptd::FrameView> pending;
+    uint32_t batch = PT_MAX_BATCH;
     uint32_t shard_cap = 0;         // ray-queue slots per shard
     uint32_t* d_counts = nullptr;   // per chain: rounds + 1 rows of queue sizes (one per shard of the chain), then as many rows of fetch cursors
     uint32_t counts_cap = 0;
@@ -105,7 +111,7 @@ struct pt_ctx {
 namespace ptd {
 int set_error(pt_ctx* ctx, int code, const std::string& msg);
 int build_accel(pt_ctx* ctx, uint32_t flags);
-int launch_trace(pt_ctx* ctx, uint32_t frame_index);
+int launch_trace(pt_ctx* ctx);     // launches the pending frames
 int launch_resolve(pt_ctx* ctx);
 int launch_postprocess(pt_ctx* ctx, float exposure);
 int env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t w, uint32_t h, uint32_t face_size);

@@ -40,13 +40,22 @@ struct alignas(16) TriRec {
     float v2x, v2y, v2z; uint32_t pad;
 };
 
+#define PT_MAX_BATCH 4      // frames traced together: consecutive pt_trace calls share their launches
+
+// what differs between the frames of a batch
+struct FrameView {
+    uint32_t frame;       // FrameIndex of that pt_trace call
+    float inv_view[16];   // column-major
+    float inv_proj[16];
+};
+
+struct FrameViewBatch { FrameView v[PT_MAX_BATCH]; };
+
 struct TraceParams {
     uint32_t width, height;
     uint32_t spp, max_bounces, rr_depth;
     float sky_scale, eps, tmin, tmax;
-    uint32_t frame;
-    float inv_view[16];   // column-major
-    float inv_proj[16];
+    uint32_t nframes;     // frames in this batch; a path is identified by frame slot * width * height + pixel
 };
 
 // scene tables as uploaded (reference layouts) + build products

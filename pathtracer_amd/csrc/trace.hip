@@ -42,6 +42,8 @@ struct Queues {
     uint32_t shard_cap;     // slots per shard; shard s owns slots [s * shard_cap, (s + 1) * shard_cap)
     uint2* primary;
     float* image; float* accum;
+    float4* partial;            // finished colour of every (frame slot, pixel) of the batch, added up in frame order by k_accumulate
+    const FrameView* views;     // the batch's frame indices and cameras
 };
 
 PT_DEV v3 mat_mul_dir(const float* m, float x, float y, float z, float w, float& ow)
@@ -55,7 +57,7 @@ PT_DEV v3 mat_mul_dir(const float* m, float x, float y, float z, float w, float&
 }
 
 // RayGen.glsl:322-342
-PT_DEV void camera_ray(const TraceParams& P, uint32_t x, uint32_t y, uint32_t sample, uint32_t& seed, v3& o, v3& d)
+PT_DEV void camera_ray(const TraceParams& P, const FrameView& V, uint32_t x, uint32_t y, uint32_t sample, uint32_t& seed, v3& o, v3& d)
 {
     float pcx = (float)x + 0.5f, pcy = (float)y + 0.5f;
     if (sample > 0) {
@@ -69,11 +71,11 @@ PT_DEV void camera_ray(const TraceParams& P, uint32_t x, uint32_t y, uint32_t sa
     float u = fdiv(pcx, (float)P.width), v = fdiv(pcy, (float)P.height);
     float dx = u * 2.0f - 1.0f, dy = v * 2.0f - 1.0f;
     float tw;
-    v3 target = mat_mul_dir(P.inv_proj, dx, dy, 1.0f, 1.0f, tw);
+    v3 target = mat_mul_dir(V.inv_proj, dx, dy, 1.0f, 1.0f, tw);
     v3 tn = normalize(target / tw);
     float dw;
-    v3 dir = mat_mul_dir(P.inv_view, tn.x, tn.y, tn.z, 0.0f, dw);
-    o = V3(P.inv_view[12], P.inv_view[13], P.inv_view[14]);
+    v3 dir = mat_mul_dir(V.inv_view, tn.x, tn.y, tn.z, 0.0f, dw);
+    o = V3(V.inv_view[12], V.inv_view[13], V.inv_view[14]);
     d = normalize(dir);
 }
 
@@ -101,33 +103,47 @@ PT_DEV uint32_t wave_append(bool alive, uint32_t* counter)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-__global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
+__global__ void k_set_views(FrameViewBatch b, FrameView* dst)
 {
-    // tile t belongs to shard t % PT_SHARDS; this chain's j-th tile is the one below
+    if (threadIdx.x < PT_MAX_BATCH) dst[threadIdx.x] = b.v[threadIdx.x];
+}
+
+// number of 8x8 tiles of the chain: tile t belongs to shard t % PT_SHARDS
+PT_DEV uint32_t chain_tiles(const TraceParams& P, const Queues& q)
+{
     uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
     uint32_t full = tiles / PT_SHARDS, rest = tiles % PT_SHARDS;
     uint32_t extra = rest > q.shard0 ? (rest - q.shard0 < q.nshards ? rest - q.shard0 : q.nshards) : 0u;
-    uint32_t nslots = (full * q.nshards + extra) * 64u;
+    return full * q.nshards + extra;
+}
+
+__global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
+{
+    const uint32_t ctiles = chain_tiles(P, q), npix = P.width * P.height;
+    const uint32_t nslots = ctiles * P.nframes * 64u;          // one tile of one frame slot per wave
     for (uint32_t base = blockIdx.x * blockDim.x; base < nslots; base += gridDim.x * blockDim.x) {
         uint32_t cs = base + threadIdx.x;
-        uint32_t j = cs >> 6;
-        uint32_t ls = j % q.nshards;                   // one tile per wave: wave-uniform
+        uint32_t jw = cs >> 6;                         // wave-uniform
+        uint32_t k = jw / ctiles, j = jw % ctiles;     // frame slot, the chain's j-th tile
+        uint32_t ls = j % q.nshards;
         uint32_t tile = (j / q.nshards) * PT_SHARDS + q.shard0 + ls;
         uint32_t slot = tile * 64u + (cs & 63u);
         uint32_t x = 0, y = 0;
         bool valid = cs < nslots && slot_to_pixel(slot, P.width, P.height, x, y);
         v3 o = V3(0.0f), d = V3(0.0f);
-        uint32_t pixel = 0;
+        uint32_t path = 0;
         if (valid) {
-            pixel = x + y * P.width;
-            uint32_t seed = pixel * P.frame;           // RayGen.glsl:314-315
-            camera_ray(P, x, y, 0, seed, o, d);
-            q.stA[pixel] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
-            q.stB[pixel] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
+            uint32_t pixel = x + y * P.width;
+            path = k * npix + pixel;
+            const FrameView& V = q.views[k];
+            uint32_t seed = pixel * V.frame;           // RayGen.glsl:314-315
+            camera_ray(P, V, x, y, 0, seed, o, d);
+            q.stA[path] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
+            q.stB[path] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
         }
         uint32_t out = (q.shard0 + ls) * q.shard_cap + wave_append(valid, &q.counts[ls]);
         if (valid) {
-            q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
+            q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(path));
             q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
         }
     }
@@ -353,23 +369,39 @@ PT_DEV void fetch_surface(const SceneView& sc, uint32_t submesh, uint32_t prim, 
     s.eta = dot(view, worldNormal) < 0.0f ? fdiv(1.0f, s.ior) : s.ior;
 }
 
-// RayGen.glsl:347-372
-PT_DEV void write_pixel(const TraceParams& P, const Queues& q, uint32_t pixel, v3 color)
+// RayGen.glsl:347-372 for every pixel of the chain and every frame of the batch, in frame order: the finished colours
+// wait in q.partial, so that a pixel's frames are added in the order of the pt_trace calls whatever order they finished in
+__global__ void __launch_bounds__(256) k_accumulate(TraceParams P, Queues q)
 {
-    float numPaths = (float)P.spp;
-    float4* acc = reinterpret_cast<float4*>(q.accum) + pixel;
-    if (P.frame > 1) {
-        float4 data = *acc;
-        color = color + V3(data.x, data.y, data.z);
-        numPaths = data.w + (float)P.spp;
-        *acc = make_float4(color.x, color.y, color.z, numPaths);
-    } else {
-        *acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t ctiles = chain_tiles(P, q), npix = P.width * P.height;
+    const uint32_t nslots = ctiles * 64u;
+    for (uint32_t cs = blockIdx.x * blockDim.x + threadIdx.x; cs < nslots; cs += gridDim.x * blockDim.x) {
+        uint32_t j = cs >> 6;
+        uint32_t tile = (j / q.nshards) * PT_SHARDS + q.shard0 + j % q.nshards;
+        uint32_t x = 0, y = 0;
+        if (!slot_to_pixel(tile * 64u + (cs & 63u), P.width, P.height, x, y)) continue;
+        uint32_t pixel = x + y * P.width;
+        float4* accp = reinterpret_cast<float4*>(q.accum) + pixel;
+        float4 acc = *accp;
+        v3 shown = V3(0.0f);
+        for (uint32_t k = 0; k < P.nframes; k++) {
+            float4 c = q.partial[k * npix + pixel];
+            v3 color = V3(c.x, c.y, c.z);
+            float numPaths = (float)P.spp;
+            if (q.views[k].frame > 1) {
+                color = color + V3(acc.x, acc.y, acc.z);
+                numPaths = acc.w + (float)P.spp;
+                acc = make_float4(color.x, color.y, color.z, numPaths);
+            } else {
+                acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            shown = color / numPaths;
+        }
+        *accp = acc;
+        float4* img = reinterpret_cast<float4*>(q.image) + pixel;
+        if (shown.x != shown.x || shown.y != shown.y || shown.z != shown.z) *img = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
+        else *img = make_float4(shown.x, shown.y, shown.z, 1.0f);
     }
-    color = color / numPaths;
-    float4* img = reinterpret_cast<float4*>(q.image) + pixel;
-    if (color.x != color.x || color.y != color.y || color.z != color.z) *img = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
-    else *img = make_float4(color.x, color.y, color.z, 1.0f);
 }
 
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
@@ -377,12 +409,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
     const uint32_t ls = blockIdx.x % q.nshards, lb = blockIdx.x / q.nshards, nb = gridDim.x / q.nshards;
     const uint32_t shard = q.shard0 + ls;
     const uint32_t n = q.counts[round * q.nshards + ls];
+    const uint32_t npix = P.width * P.height;
     for (uint32_t base = lb * SHADE_BLOCK; base < n; base += nb * SHADE_BLOCK) {
         uint32_t slot = shard * q.shard_cap + base + threadIdx.x;
         bool valid = base + threadIdx.x < n;
         bool alive = false;
         v3 o = V3(0.0f), d = V3(0.0f);
-        uint32_t pixel = 0;
+        uint32_t pixel = 0;            // the path: frame slot * pixels + pixel
         float lag_bits = 0.0f;
         if (valid && f2u(q.hits[slot].w) == DEFERRED) valid = false;     // suspended: the traversal kernel has queued it for the next round
         if (valid) {
@@ -399,14 +432,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
             uint32_t tri = f2u(h.w);
             bool done = false;
             if (tri == MISS) {
-                if (bounce == 0 && sample == 0) q.primary[pixel] = make_uint2(MISS, MISS);
+                if (bounce == 0 && sample == 0 && pixel / npix + 1u == P.nframes) q.primary[pixel % npix] = make_uint2(MISS, MISS);
                 v3 sky = sample_env(sc, d) * P.sky_scale;            // RayGen.glsl:128-135
                 rad = rad + sky * thr;
                 done = true;
             } else {
                 const TriRec* tr = sc.tris + tri;
                 uint32_t submesh = tr->submesh, prim = tr->prim;
-                if (bounce == 0 && sample == 0) q.primary[pixel] = make_uint2(submesh, prim);
+                if (bounce == 0 && sample == 0 && pixel / npix + 1u == P.nframes) q.primary[pixel % npix] = make_uint2(submesh, prim);
                 Surf s;
                 v3 emission, N;
                 fetch_surface(sc, submesh, prim, h.y, h.z, d, s, emission, N);
@@ -442,14 +475,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
                 sample++;
                 if (sample < P.spp) {
                     q.stC[pixel] = make_float4(color.x, color.y, color.z, 0.0f);
-                    uint32_t x = pixel % P.width, y = pixel / P.width;
-                    camera_ray(P, x, y, sample, seed, o, d);
+                    uint32_t px = pixel % npix;
+                    camera_ray(P, q.views[pixel / npix], px % P.width, px / P.width, sample, seed, o, d);
                     thr = V3(1.0f);
                     rad = V3(0.0f);
                     bounce = 0;
                     alive = true;
                 } else {
-                    write_pixel(P, q, pixel, color);
+                    q.partial[pixel] = make_float4(color.x, color.y, color.z, 0.0f);
                 }
             } else {
                 alive = true;
@@ -516,8 +549,14 @@ SceneView scene_view(const pt_ctx* ctx)
     return sv;
 }
 
-int launch_trace(pt_ctx* ctx, uint32_t frame)
+// launches the frames queued by pt_trace as one batch
+int launch_trace(pt_ctx* ctx)
 {
+    if (ctx->pending.empty()) return PT_OK;
+    FrameViewBatch views{};
+    const uint32_t nframes = (uint32_t)ctx->pending.size();
+    for (uint32_t k = 0; k < nframes; k++) views.v[k] = ctx->pending[k];
+    ctx->pending.clear();          // before anything below synchronises, which would flush again
     const pt_params& pp = ctx->params;
     uint32_t npix = ctx->width * ctx->height;
     // more rounds than the longest path needs: a path falls a round behind each time its ray is suspended
@@ -526,9 +565,7 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     P.width = ctx->width; P.height = ctx->height;
     P.spp = pp.spp_per_frame; P.max_bounces = pp.max_bounces; P.rr_depth = pp.rr_depth;
     P.sky_scale = pp.sky_scale; P.eps = pp.eps; P.tmin = pp.tmin; P.tmax = pp.tmax;
-    P.frame = frame;
-    std::memcpy(P.inv_view, ctx->camera + 48, 64);
-    std::memcpy(P.inv_proj, ctx->camera + 64, 64);
+    P.nframes = nframes;
     SceneView sv = scene_view(ctx);
 
     const bool prof = ctx->profiling != 0;
@@ -572,23 +609,26 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
     }
 
     // workgroup b of a chain's grid serves the chain's shard b % spc
-    auto chain_grid = [&](uint32_t block, uint32_t cap_total) {
-        uint32_t per_shard = (npix / PT_SHARDS + block) / block;
+    auto chain_grid = [&](uint32_t block, uint32_t cap_total, uint32_t frames) {
+        uint32_t per_shard = (npix * frames / PT_SHARDS + block) / block;
         uint32_t cap_per_shard = cap_total / PT_SHARDS ? cap_total / PT_SHARDS : 1u;
         if (per_shard > cap_per_shard) per_shard = cap_per_shard;
         return per_shard * spc;
     };
     static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 28u;
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
-    uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu);
-    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, max_blocks);
+    uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
+    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, max_blocks, nframes);
+    // a chain's share of the spill area and of the suspension records is laid out for a full batch, so that a
+    // short batch launched while a full one is still running stays inside its own chain's share
+    const uint32_t ext_blocks_max = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, PT_MAX_BATCH);
     {
-        int rc = ensure_spill(ctx, ext_blocks * chains);
+        int rc = ensure_spill(ctx, ext_blocks_max * chains);
         if (rc) return rc;
     }
     // records of suspended traversals: per chain two pools (the round's own and the next round's), per shard one
     // record for each ray the shard's waves can suspend in a launch
-    const uint32_t susp_cap = (ext_blocks / spc) * PT_CUT_LANES;
+    const uint32_t susp_cap = (ext_blocks_max / spc) * PT_CUT_LANES;
     const uint32_t susp_words = PT_SUSPEND_STATE_WORDS + 2u * ctx->stack_entries;
     {
         size_t need = (size_t)chains * 2 * spc * susp_cap * susp_words;
@@ -641,13 +681,16 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
         q.shard_cap = ctx->shard_cap;
         q.primary = ctx->d_primary;
         q.image = ctx->d_image; q.accum = ctx->d_accum;
-        uint2* spill = ctx->d_spill + (size_t)c * ext_blocks * (ctx->stack_entries * 64);
+        q.partial = ctx->d_partial;
+        q.views = ctx->d_views + c * PT_MAX_BATCH;
+        k_set_views<<<1, 64, 0, st>>>(views, ctx->d_views + c * PT_MAX_BATCH);
+        uint2* spill = ctx->d_spill + (size_t)c * ext_blocks_max * (ctx->stack_entries * 64);
 
         PT_HIP(ctx, mark());
         {
             q.rayO_in = q.rayO_out = ctx->d_rayO[0];
             q.rayD_in = q.rayD_out = ctx->d_rayD[0];
-            uint32_t blocks = ((tiles / chains + spc) * 64u + 255u) / 256u;
+            uint32_t blocks = ((tiles / chains + spc) * nframes * 64u + 255u) / 256u;
             if (blocks > max_blocks) blocks = max_blocks;
             k_raygen<<<blocks, 256, 0, st>>>(P, q);
         }
@@ -680,6 +723,11 @@ int launch_trace(pt_ctx* ctx, uint32_t frame)
             q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
             k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
             PT_HIP(ctx, mark());
+        }
+        {
+            uint32_t blocks = ((tiles / chains + spc) * 64u + 255u) / 256u;
+            if (blocks > max_blocks) blocks = max_blocks;
+            k_accumulate<<<blocks, 256, 0, st>>>(P, q);
         }
         k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, deferred, ctx->d_total_rays);
         if (prof) PT_HIP(ctx, hipMemcpyAsync(slot->h_counts + c * chain_words, counts, chain_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

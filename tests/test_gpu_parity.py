@@ -283,6 +283,52 @@ def test_image_does_not_depend_on_the_chain_count(backend, cornell, cameras, cha
         backend.set_chains(3)
 
 
+@pytest.mark.parametrize("batch", [1, 2, 3, 4])
+def test_image_does_not_depend_on_frame_batching(backend, cornell, cameras, batch):
+    """Up to four consecutive trace() calls share their launches.  Seven frames issued with no synchronisation in
+    between, the camera and (once) the parameters changing from frame to frame, so that short batches are launched
+    while full ones are still running: same bits as the oracle tracing them one by one."""
+    def moved(cam, k):
+        cam = np.array(cam, np.float32).reshape(5, 4, 4).copy()
+        cam[3, 3, 0] += 0.01 * k          # InverseView, column-major: translation x
+        cam[3, 3, 1] -= 0.004 * k
+        return cam.reshape(-1)
+    try:
+        backend.set_batch(batch)
+        for W, H in ((128, 128), (200, 120)):
+            backend.scene_upload(cornell)
+            backend.build_accel()
+            backend.resize(W, H)
+            p = Params.reference(spp_per_frame=2, max_bounces=5)
+            backend.set_params(p)
+            r0 = backend.ray_count()
+            calls = []
+            for f in range(1, 8):
+                if f == 6:
+                    p = Params.reference(spp_per_frame=1, max_bounces=3)
+                    backend.set_params(p)
+                cam = moved(cameras["512x512"], f)
+                backend.set_camera(cam)
+                backend.trace(f)
+                calls.append((f, cam, p))
+            got_accum, got_image, got_ids = backend.read_accum(), backend.read_image(), backend.read_primary_ids()
+            rays = backend.ray_count() - r0
+            o = oracle_lib.Oracle(cornell)
+            o.resize(W, H)
+            for f, cam, q in calls:
+                o.set_camera(cam)
+                o.set_params(q)
+                o.trace(f)
+            assert rays == o.ray_count()
+            assert np.array_equal(got_ids, o.read_primary_ids())
+            assert np.array_equal(bits(got_accum), bits(o.read_accum()))
+            assert np.array_equal(bits(got_image), bits(o.read_image()))
+    finally:
+        backend.set_batch(4)
+    with pytest.raises(BackendError):
+        backend.set_batch(5)
+
+
 @pytest.mark.parametrize("defer", ["0", "1", "4"])
 def test_image_does_not_depend_on_ray_suspension(cornell, cameras, monkeypatch, defer):
     """PT_DEFER = rounds a path may fall behind because the tail of a traversal launch suspended its ray (default 2;
