@@ -40,7 +40,9 @@ struct alignas(16) TriRec {
     float v2x, v2y, v2z; uint32_t pad;
 };
 
+#ifndef PT_MAX_BATCH
 #define PT_MAX_BATCH 4      // frames traced together: consecutive pt_trace calls share their launches
+#endif
 
 // what differs between the frames of a batch
 struct FrameView {

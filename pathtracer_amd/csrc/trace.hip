@@ -615,7 +615,7 @@ int launch_trace(pt_ctx* ctx)
         if (per_shard > cap_per_shard) per_shard = cap_per_shard;
         return per_shard * spc;
     };
-    static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 28u;
+    static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 40u;
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
     uint32_t sh_blocks = chain_grid(SHADE_BLOCK, max_blocks, nframes);
