@@ -319,67 +319,67 @@ PT_DEV bool wins_tie(const TriRec* __restrict__ tris, uint32_t cand, uint32_t be
 }
 
 // Triangle phase, run by the whole wave.  Every lane with a pending leaf owns 1..PT_LEAF_MAX work items (its
-// triangles); the items are numbered through the wave and item j is tested by lane j % 64 in pass
-// j / 64, with the owner's ray fetched by lane permutes.  The owner then collects the distances of
-// its items, keeps the closest under the usual rules, and fetches that one's barycentric terms.
+// triangles); the items are numbered through the wave in lane order and item j is tested by lane j, with the
+// owner's ray fetched by lane permutes.  The owner then collects the distances of its items, keeps the closest
+// under the usual rules, and fetches that one's barycentric terms.  One call tests at most 64 items: lanes whose
+// items do not fit keep their leaf pending for the next call (returns whether this lane's leaf was tested).
 // `owner` is this wave's PT_OWNER_BYTES-byte LDS work list.  Must be called in wave-uniform control flow.
 template <bool STATS>
-PT_DEV void leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, uint16_t* owner, uint32_t lane, uint32_t& stat_tris)
+PT_DEV bool leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, uint16_t* owner, uint32_t lane, uint32_t& stat_tris)
 {
     const uint32_t first = s.pend & 0x0FFFFFFFu;
-    const uint32_t cnt = has_pend ? ((s.pend >> 28) & 7u) + 1u : 0u;
+    uint32_t cnt = has_pend ? ((s.pend >> 28) & 7u) + 1u : 0u;
     // exclusive prefix sum of cnt (0..PT_LEAF_MAX) over the lanes, from one ballot per bit
     unsigned long long b0 = __ballot((cnt & 1u) != 0), b1 = __ballot((cnt & 2u) != 0), b2 = __ballot((cnt & 4u) != 0);
     uint32_t off = lanes_below(b0) + 2u * lanes_below(b1) + 4u * lanes_below(b2);
-    uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
     if (PT_LEAF_MAX >= 8u) {
         unsigned long long b3 = __ballot((cnt & 8u) != 0);
         off += 8u * lanes_below(b3);
-        total += 8u * (uint32_t)__popcll(b3);
     }
+    const bool mine = has_pend && off + cnt <= 64u;       // the lanes taken are a prefix of the pending lanes
+    if (!mine) cnt = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < PT_LEAF_MAX; k++)
         if (k < cnt) owner[off + k] = (uint16_t)(lane | (k << 6));
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), 63 - __builtin_clzll(__ballot(mine) | 1ull));
     __syncthreads();
     const uint32_t kpack = (uint32_t)s.rp.kx | ((uint32_t)s.rp.ky << 2) | ((uint32_t)s.rp.kz << 4);
-    for (uint32_t p0 = 0; p0 < total; p0 += 64u) {
-        // ---- test item p0 + lane
-        const uint32_t j = p0 + lane;
-        const bool work = j < total;
-        const uint32_t ow = work ? owner[j] : lane;
-        const uint32_t src = ow & 63u, k = ow >> 6;
-        const uint32_t w_first = lane_read(first, src);
-        v3 wo = V3(lane_read(s.o.x, src), lane_read(s.o.y, src), lane_read(s.o.z, src));
-        RayPre wr;
-        wr.Sx = lane_read(s.rp.Sx, src); wr.Sy = lane_read(s.rp.Sy, src); wr.Sz = lane_read(s.rp.Sz, src);
-        const uint32_t wk = lane_read(kpack, src);
-        wr.kx = (int)(wk & 3u); wr.ky = (int)((wk >> 2) & 3u); wr.kz = (int)(wk >> 4);
-        const float w_tmin = lane_read(s.tmin, src);
-        float wt = __builtin_inff(), wV = 0.0f, wW = 0.0f, wdet = 1.0f;
-        if (work) {
-            const float4* tp = reinterpret_cast<const float4*>(tris + w_first + k);
-            float4 a = tp[0], b = tp[1], c = tp[2];
-            if (STATS) stat_tris++;
-            float t, V, W, det;
-            if (tri_test(wr, wo, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), w_tmin, t, V, W, det)) { wt = t; wV = V; wW = W; wdet = det; }
-        }
-        // ---- owners collect
-        uint32_t win = lane;
-        bool won = false;
-#pragma unroll
-        for (uint32_t kk = 0; kk < PT_LEAF_MAX; kk++) {
-            const uint32_t jj = off + kk;
-            const float tk = lane_read(wt, jj & 63u);
-            if (kk < cnt && (jj - p0) < 64u && tk < s.tmax) {
-                bool take = tk < s.best.t;
-                if (tk == s.best.t && s.best.tri != 0xFFFFFFFFu) take = wins_tie(tris, first + kk, s.best.tri);
-                if (take) { s.best.t = tk; s.best.tri = first + kk; win = jj & 63u; won = true; }
-            }
-        }
-        const float gV = lane_read(wV, win), gW = lane_read(wW, win), gdet = lane_read(wdet, win);
-        if (won) { s.bV = gV; s.bW = gW; s.bdet = gdet; }
+    // ---- test item `lane`
+    const bool work = lane < total;
+    const uint32_t ow = work ? owner[lane] : lane;
+    const uint32_t src = ow & 63u, k = ow >> 6;
+    const uint32_t w_first = lane_read(first, src);
+    v3 wo = V3(lane_read(s.o.x, src), lane_read(s.o.y, src), lane_read(s.o.z, src));
+    RayPre wr;
+    wr.Sx = lane_read(s.rp.Sx, src); wr.Sy = lane_read(s.rp.Sy, src); wr.Sz = lane_read(s.rp.Sz, src);
+    const uint32_t wk = lane_read(kpack, src);
+    wr.kx = (int)(wk & 3u); wr.ky = (int)((wk >> 2) & 3u); wr.kz = (int)(wk >> 4);
+    const float w_tmin = lane_read(s.tmin, src);
+    float wt = __builtin_inff(), wV = 0.0f, wW = 0.0f, wdet = 1.0f;
+    if (work) {
+        const float4* tp = reinterpret_cast<const float4*>(tris + w_first + k);
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) stat_tris++;
+        float t, V, W, det;
+        if (tri_test(wr, wo, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), w_tmin, t, V, W, det)) { wt = t; wV = V; wW = W; wdet = det; }
     }
+    // ---- owners collect
+    uint32_t win = lane;
+    bool won = false;
+#pragma unroll
+    for (uint32_t kk = 0; kk < PT_LEAF_MAX; kk++) {
+        const uint32_t jj = off + kk;
+        const float tk = lane_read(wt, jj & 63u);
+        if (kk < cnt && tk < s.tmax) {
+            bool take = tk < s.best.t;
+            if (tk == s.best.t && s.best.tri != 0xFFFFFFFFu) take = wins_tie(tris, first + kk, s.best.tri);
+            if (take) { s.best.t = tk; s.best.tri = first + kk; win = jj & 63u; won = true; }
+        }
+    }
+    const float gV = lane_read(wV, win), gW = lane_read(wW, win), gdet = lane_read(wdet, win);
+    if (won) { s.bV = gV; s.bW = gW; s.bdet = gdet; }
     __syncthreads();
+    return mine;
 }
 
 PT_DEV void finish_hit(Trav& s)
@@ -479,8 +479,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         unsigned long long nodem = __ballot(has && s.cur < PT_CUR_NONE);
         if (pendm != 0 && ((uint32_t)__popcll(pendm) >= PT_LEAF_MIN || nodem == 0)) {
             if (STATS && wave_stats && lane == 0) { wave_stats->leaf_phases++; wave_stats->leaf_lanes += (uint32_t)__popcll(pendm); }
-            leaf_phase<STATS>(s, has_pend, tris, owner, lane, stat_tris);
-            if (has_pend) {
+            if (leaf_phase<STATS>(s, has_pend, tris, owner, lane, stat_tris)) {
                 s.pend = 0;
                 // the hit may have come closer than the subtree this lane went on to meanwhile
                 if (s.cur != PT_CUR_NONE && s.cur_key > s.best.t) trav_pop(s, lds_stack, stride, ovf);
