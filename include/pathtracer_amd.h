@@ -25,10 +25,17 @@ extern "C" {
 #define PT_ERR_TOO_LARGE 5    /* size beyond a documented limit */
 
 /* binding 9: sampler2D u_Textures[] (ClosestHit.glsl:15).  RGBA8 UNORM texels,
- * row 0 first; sampled bilinear / repeat / level 0. */
+ * row 0 first; sampled at level 0, bilinear with repeat unless flags say otherwise (the
+ * reference's samplers are made by its engine from the glTF sampler objects). */
+#define PT_TEX_WRAP_REPEAT 0u
+#define PT_TEX_WRAP_CLAMP 1u
+#define PT_TEX_WRAP_MIRROR 2u
+#define PT_TEX_WRAP_S(mode) (mode)          /* wrap mode of u: bits 0-1 */
+#define PT_TEX_WRAP_T(mode) ((mode) << 2)   /* wrap mode of v: bits 2-3 */
+#define PT_TEX_NEAREST 16u                  /* nearest texel instead of bilinear */
 typedef struct pt_texture_desc {
     uint32_t width, height;
-    uint32_t flags;            /* reserved, must be 0 */
+    uint32_t flags;            /* PT_TEX_* above; 0 = bilinear, repeat */
     uint32_t pad_;
     const uint8_t* rgba8;
 } pt_texture_desc;

@@ -33,6 +33,8 @@ int pth_mesh_tables(pth_mesh* m, const float* layer_transform, float* vertices, 
                     uint32_t* submeshes, uint32_t* index_counts, float* xforms, float* materials);
 const char* pth_mesh_submesh_name(pth_mesh* m, uint32_t i);
 const char* pth_mesh_texture_uri(pth_mesh* m, uint32_t i);
+/* sampler state of glTF image i as PT_TEX_* flags (from the sampler of the first glTF texture that uses the image) */
+uint32_t pth_mesh_texture_sampler(pth_mesh* m, uint32_t i);
 /* supplies decoded RGBA8 texels for glTF image i (this layer has no JPEG/PNG decoder) */
 int pth_mesh_set_texture(pth_mesh* m, uint32_t i, uint32_t width, uint32_t height, const uint8_t* rgba8);
 /* edits one 22-word material record (the ImGui material sliders, RayTracingLayer.cpp:536-564) */

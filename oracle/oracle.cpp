@@ -77,23 +77,49 @@ static void build_world_tris(Ctx& c)
     }
 }
 
-// texture(sampler2D, uv): bilinear, repeat, level 0, RGBA8 UNORM (no sRGB decode)
+// sampler state of a texture (flags): wrap mode of u in bits 0-1 and of v in bits 2-3 (0 repeat, 1 clamp to
+// edge, 2 mirrored repeat), bit 4 = nearest instead of bilinear.  The reference's sampler objects are created by
+// its absent engine; glTF's sampler fields map onto these (parity unpinned).
+static float wrap_coord(float u, uint32_t mode)
+{
+    if (mode == 0u) {
+        float f = u - floorf(u);
+        return f >= 0.0f ? f : 0.0f;
+    }
+    if (mode == 2u) {
+        float h = u * 0.5f;
+        float t = (h - floorf(h)) * 2.0f;
+        float m = t <= 1.0f ? t : 2.0f - t;
+        return m >= 0.0f ? m : 0.0f;
+    }
+    if (!(u >= -1.0f)) u = -1.0f;
+    return u > 2.0f ? 2.0f : u;
+}
+
+static int wrap_index(int i, int n, uint32_t mode)
+{
+    if (mode == 0u) {
+        if (i < 0) i += n;
+        if (i >= n) i -= n;
+        return i;
+    }
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// texture(sampler2D, uv): level 0, RGBA8 UNORM (no sRGB decode); bilinear + repeat unless the flags say otherwise
 static vec4 sample_texture(const Texture& tx, float u, float v)
 {
-    float uu = u - floorf(u), vv = v - floorf(v);
-    if (!(uu >= 0.0f)) uu = 0.0f;
-    if (!(vv >= 0.0f)) vv = 0.0f;
-    float x = uu * (float)tx.w - 0.5f, y = vv * (float)tx.h - 0.5f;
+    const uint32_t ws = tx.flags & 3u, wt = (tx.flags >> 2) & 3u;
+    const bool nearest = (tx.flags & 16u) != 0;
+    float uu = wrap_coord(u, ws), vv = wrap_coord(v, wt);
+    float x = uu * (float)tx.w, y = vv * (float)tx.h;
+    if (!nearest) { x = x - 0.5f; y = y - 0.5f; }
     float x0f = floorf(x), y0f = floorf(y);
-    float fx = x - x0f, fy = y - y0f;
+    float fx = nearest ? 0.0f : x - x0f, fy = nearest ? 0.0f : y - y0f;
     int x0 = (int)x0f, y0 = (int)y0f;
-    int x1 = x0 + 1, y1 = y0 + 1;
-    if (x0 < 0) x0 = (int)tx.w - 1;
-    if (y0 < 0) y0 = (int)tx.h - 1;
-    if (x1 >= (int)tx.w) x1 = 0;
-    if (y1 >= (int)tx.h) y1 = 0;
-    if (x0 >= (int)tx.w) x0 = 0;
-    if (y0 >= (int)tx.h) y0 = 0;
+    int x1 = nearest ? x0 : x0 + 1, y1 = nearest ? y0 : y0 + 1;
+    x0 = wrap_index(x0, (int)tx.w, ws); x1 = wrap_index(x1, (int)tx.w, ws);
+    y0 = wrap_index(y0, (int)tx.h, wt); y1 = wrap_index(y1, (int)tx.h, wt);
     auto texel = [&](int xx, int yy, int ch) { return (float)tx.px[((size_t)yy * tx.w + xx) * 4 + ch] * (1.0f / 255.0f); };
     float out[4];
     for (int ch = 0; ch < 4; ch++) {
@@ -469,6 +495,17 @@ void orc_det_math(int fn, const float* x, const float* y, float* out, uint32_t n
         case 7: out[i] = det_tan(x[i]); break;
         default: out[i] = round_to_half(x[i]); break;
         }
+    }
+}
+
+void orc_sample_texture(const orc_texture_desc* tex, const float* uv, uint32_t n, float* rgba)
+{
+    Texture t;
+    t.w = tex->width; t.h = tex->height; t.flags = tex->flags;
+    t.px.assign(tex->rgba8, tex->rgba8 + (size_t)tex->width * tex->height * 4);
+    for (uint32_t i = 0; i < n; i++) {
+        vec4 c = sample_texture(t, uv[2 * i], uv[2 * i + 1]);
+        rgba[4 * i] = c.x; rgba[4 * i + 1] = c.y; rgba[4 * i + 2] = c.z; rgba[4 * i + 3] = c.w;
     }
 }
 

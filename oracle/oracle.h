@@ -15,7 +15,7 @@ extern "C" {
 
 typedef struct orc_texture_desc {
     uint32_t width, height;
-    uint32_t flags;            /* reserved, 0 */
+    uint32_t flags;            /* sampler state: wrap of u in bits 0-1, of v in bits 2-3 (0 repeat, 1 clamp, 2 mirror), bit 4 nearest */
     uint32_t pad_;
     const uint8_t* rgba8;      /* width*height*4 bytes, row 0 first */
 } orc_texture_desc;
@@ -69,6 +69,8 @@ uint32_t orc_pcg_hash(uint32_t* seed);
 float orc_random_value(uint32_t* seed);
 /* fn: 0 sin, 1 cos, 2 log, 3 exp, 4 pow(x, y) */
 void orc_det_math(int fn, const float* x, const float* y, float* out, uint32_t n);   /* fn: 0 sin 1 cos 2 log 3 exp 4 pow 5 atan2 6 acos 7 tan 8 round-to-half */
+/* texture(sampler2D, uv) of one texture at n coordinates (uv = n * 2 floats) -> n * 4 floats */
+void orc_sample_texture(const orc_texture_desc* tex, const float* uv, uint32_t n, float* rgba);
 /* PostProcessing.glsl, EquirectangularToCubeMap.glsl, PreethamSky.glsl (oracle/passes.h) */
 void orc_postprocess(const float* rgba, uint32_t num_pixels, float exposure, uint8_t* rgba8);
 void orc_equirect_to_cube(const float* rgba, uint32_t w, uint32_t h, uint32_t face_size, float* cube);

@@ -290,7 +290,8 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* s)
         }
     }
     for (uint32_t t = 0; t < s->num_textures; t++)
-        if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 || s->textures[t].flags != 0)
+        if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 ||
+            (s->textures[t].flags & ~31u) || (s->textures[t].flags & 3u) == 3u || ((s->textures[t].flags >> 2) & 3u) == 3u)
             return set_error(ctx, PT_ERR_INVALID, "texture " + std::to_string(t) + " is empty or has unknown flags");
 
     PT_SYNC(ctx);

@@ -242,26 +242,51 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
     }
 }
 
-// texture(sampler2D, uv): bilinear, repeat, level 0, RGBA8 UNORM
+// sampler state of a texture (pt_texture_desc.flags): wrap mode of u in bits 0-1 and of v in bits 2-3
+// (0 repeat, 1 clamp to edge, 2 mirrored repeat), bit 4 = nearest instead of bilinear
+PT_DEV float wrap_coord(float u, uint32_t mode)
+{
+    if (mode == 0u) {
+        float f = u - floorf(u);
+        return f >= 0.0f ? f : 0.0f;                  // NaN -> 0
+    }
+    if (mode == 2u) {
+        float h = u * 0.5f;
+        float t = (h - floorf(h)) * 2.0f;             // u modulo 2
+        float m = t <= 1.0f ? t : 2.0f - t;
+        return m >= 0.0f ? m : 0.0f;
+    }
+    if (!(u >= -1.0f)) u = -1.0f;                     // clamp: the texel indices are clamped below, this keeps them in int range
+    return u > 2.0f ? 2.0f : u;
+}
+
+PT_DEV int wrap_index(int i, int n, uint32_t mode)
+{
+    if (mode == 0u) {
+        if (i < 0) i += n;
+        if (i >= n) i -= n;
+        return i;
+    }
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// texture(sampler2D, uv): level 0, RGBA8 UNORM; bilinear + repeat unless the texture's flags say otherwise
 PT_DEV float4 sample_texture(const SceneView& sc, int tex, float u, float v)
 {
     const uint32_t* tt = sc.tex_table + tex * 4;
-    uint32_t off = tt[0], w = tt[1], h = tt[2];
+    uint32_t off = tt[0], w = tt[1], h = tt[2], flags = tt[3];
+    const uint32_t ws = flags & 3u, wt = (flags >> 2) & 3u;
+    const bool nearest = (flags & 16u) != 0;
     const uint32_t* px = reinterpret_cast<const uint32_t*>(sc.tex_pool) + off;
-    float uu = u - floorf(u), vv = v - floorf(v);
-    if (!(uu >= 0.0f)) uu = 0.0f;
-    if (!(vv >= 0.0f)) vv = 0.0f;
-    float x = uu * (float)w - 0.5f, y = vv * (float)h - 0.5f;
+    float uu = wrap_coord(u, ws), vv = wrap_coord(v, wt);
+    float x = uu * (float)w, y = vv * (float)h;
+    if (!nearest) { x = x - 0.5f; y = y - 0.5f; }
     float x0f = floorf(x), y0f = floorf(y);
-    float fx = x - x0f, fy = y - y0f;
+    float fx = nearest ? 0.0f : x - x0f, fy = nearest ? 0.0f : y - y0f;
     int x0 = (int)x0f, y0 = (int)y0f;
-    int x1 = x0 + 1, y1 = y0 + 1;
-    if (x0 < 0) x0 = (int)w - 1;
-    if (y0 < 0) y0 = (int)h - 1;
-    if (x1 >= (int)w) x1 = 0;
-    if (y1 >= (int)h) y1 = 0;
-    if (x0 >= (int)w) x0 = 0;
-    if (y0 >= (int)h) y0 = 0;
+    int x1 = nearest ? x0 : x0 + 1, y1 = nearest ? y0 : y0 + 1;
+    x0 = wrap_index(x0, (int)w, ws); x1 = wrap_index(x1, (int)w, ws);
+    y0 = wrap_index(y0, (int)h, wt); y1 = wrap_index(y1, (int)h, wt);
     uint32_t p00 = px[(size_t)y0 * w + x0], p10 = px[(size_t)y0 * w + x1];
     uint32_t p01 = px[(size_t)y1 * w + x0], p11 = px[(size_t)y1 * w + x1];
     float out[4];

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_host.so")
 
 EXPORTS = [
-    "pth_mesh_load", "pth_mesh_free", "pth_mesh_counts", "pth_mesh_tables", "pth_mesh_submesh_name", "pth_mesh_texture_uri",
+    "pth_mesh_load", "pth_mesh_free", "pth_mesh_counts", "pth_mesh_tables", "pth_mesh_submesh_name", "pth_mesh_texture_uri", "pth_mesh_texture_sampler",
     "pth_mesh_set_texture", "pth_mesh_set_material", "pth_camera_matrices", "pth_layer_create", "pth_layer_destroy",
     "pth_layer_set_viewport", "pth_layer_set_params", "pth_layer_set_accumulate", "pth_layer_set_camera_position",
     "pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render", "pth_layer_frame_index",
@@ -49,6 +49,8 @@ def load_library():
     L.pth_mesh_submesh_name.restype = C.c_char_p
     L.pth_mesh_texture_uri.argtypes = [vp, C.c_uint32]
     L.pth_mesh_texture_uri.restype = C.c_char_p
+    L.pth_mesh_texture_sampler.argtypes = [vp, C.c_uint32]
+    L.pth_mesh_texture_sampler.restype = C.c_uint32
     L.pth_mesh_set_texture.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
     L.pth_mesh_set_material.argtypes = [vp, C.c_uint32, fp]
     L.pth_camera_matrices.argtypes = [C.POINTER(CameraSpec), C.c_uint32, C.c_uint32, fp]
@@ -130,6 +132,10 @@ class MeshSource:
 
     def texture_uris(self):
         return [self.L.pth_mesh_texture_uri(self.h, i).decode() for i in range(self.counts()[4])]
+
+    def texture_samplers(self):
+        """Sampler state per glTF image as PT_TEX_* flags (wrap of u bits 0-1, of v bits 2-3, bit 4 nearest)."""
+        return [int(self.L.pth_mesh_texture_sampler(self.h, i)) for i in range(self.counts()[4])]
 
     def set_texture(self, i, rgba8):
         t = np.ascontiguousarray(rgba8, np.uint8)

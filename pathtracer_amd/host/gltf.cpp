@@ -193,6 +193,22 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
             t.Uri = im.gets("uri", "");
             m_Textures.push_back(std::move(t));
         }
+    // sampler state travels with the image: wrapS / wrapT 10497 repeat (default), 33071 clamp to edge, 33648 mirrored
+    // repeat; magFilter 9728 nearest, otherwise linear.  Mip-mapping (minFilter) has no counterpart: level 0 only.
+    if (const Json* tj = g.find("textures")) {
+        const Json* sj = g.find("samplers");
+        std::vector<bool> seen(m_Textures.size(), false);
+        auto wrap = [](int64_t v) -> uint32_t { return v == 33071 ? 1u : (v == 33648 ? 2u : 0u); };
+        for (const Json& t : tj->arr) {
+            int64_t src = t.geti("source", -1), si = t.geti("sampler", -1);
+            if (src < 0 || (size_t)src >= m_Textures.size() || seen[(size_t)src]) continue;
+            seen[(size_t)src] = true;
+            if (!sj || si < 0 || (size_t)si >= sj->size()) continue;
+            const Json& sm = sj->at((size_t)si);
+            m_Textures[(size_t)src].SamplerFlags = wrap(sm.geti("wrapS", 10497)) | (wrap(sm.geti("wrapT", 10497)) << 2) |
+                                                   (sm.geti("magFilter", 9729) == 9728 ? 16u : 0u);
+        }
+    }
     auto image_of = [&](const Json* ref) -> int32_t {
         if (!ref) return -1;
         int64_t ti = ref->geti("index", -1);

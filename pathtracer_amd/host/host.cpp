@@ -224,7 +224,7 @@ AccelerationStructure::AccelerationStructure(Ref<Device> device, const Accelerat
         bool have = !tex[i].RGBA8.empty();
         td[i].width = have ? tex[i].Width : 1;
         td[i].height = have ? tex[i].Height : 1;
-        td[i].flags = 0;
+        td[i].flags = tex[i].SamplerFlags;
         td[i].pad_ = 0;
         td[i].rgba8 = have ? tex[i].RGBA8.data() : white;
     }

@@ -75,6 +75,7 @@ struct TextureData {
     std::string Uri;              // as written in the glTF file
     uint32_t Width = 0, Height = 0;
     std::vector<uint8_t> RGBA8;   // empty until a decoder fills it
+    uint32_t SamplerFlags = 0;    // PT_TEX_* of pathtracer_amd.h, from the glTF sampler of the first texture that uses the image
 };
 
 // glTF 2.0 import: .gltf JSON with embedded (base64) or external buffers.

@@ -102,6 +102,7 @@ int pth_mesh_tables(pth_mesh* m, const float* layer, float* vertices, uint32_t* 
 
 const char* pth_mesh_submesh_name(pth_mesh* m, uint32_t i) { return m->source->GetSubMeshes().at(i).Name.c_str(); }
 const char* pth_mesh_texture_uri(pth_mesh* m, uint32_t i) { return m->source->GetTextures().at(i).Uri.c_str(); }
+uint32_t pth_mesh_texture_sampler(pth_mesh* m, uint32_t i) { return i < m->source->GetTextures().size() ? m->source->GetTextures()[i].SamplerFlags : 0u; }
 
 int pth_mesh_set_texture(pth_mesh* m, uint32_t i, uint32_t w, uint32_t h, const uint8_t* rgba8)
 {

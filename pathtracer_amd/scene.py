@@ -68,6 +68,7 @@ class SceneData:
         self.xforms = np.ascontiguousarray(xforms, np.float32).reshape(-1, 12)
         self.materials = np.ascontiguousarray(materials, np.float32).reshape(-1, MATERIAL_WORDS)
         self.textures = [np.ascontiguousarray(t, np.uint8) for t in textures]   # each (h, w, 4)
+        self.texture_flags = [0] * len(self.textures)   # sampler state per texture: PT_TEX_* of include/pathtracer_amd.h
         self.env = None if env is None else np.ascontiguousarray(env, np.float32)   # (6, n, n, 4)
         self.names = list(names) if names is not None else ["submesh%d" % i for i in range(len(self.submeshes))]
         assert len(self.submeshes) == len(self.index_counts) == len(self.xforms)
@@ -90,7 +91,7 @@ class SceneData:
         tex = (TextureDesc * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             tex[i].height, tex[i].width = t.shape[0], t.shape[1]
-            tex[i].flags = 0
+            tex[i].flags = int(self.texture_flags[i])
             tex[i].rgba8 = t.ctypes.data_as(C.POINTER(C.c_uint8))
         d.textures = tex
         d.num_textures = len(self.textures)

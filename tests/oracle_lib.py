@@ -66,6 +66,8 @@ def lib():
     L.orc_det_math.restype = None
     L.orc_postprocess.argtypes = [fp, C.c_uint32, C.c_float, C.POINTER(C.c_uint8)]
     L.orc_postprocess.restype = None
+    L.orc_sample_texture.argtypes = [vp, fp, C.c_uint32, fp]
+    L.orc_sample_texture.restype = None
     L.orc_equirect_to_cube.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, fp]
     L.orc_equirect_to_cube.restype = None
     L.orc_preetham_sky.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32, fp]
@@ -181,6 +183,19 @@ def det_math(fn, x, y=None):
     y = np.zeros_like(x) if y is None else np.ascontiguousarray(y, np.float32).reshape(-1)
     out = np.empty_like(x)
     lib().orc_det_math(fn, _fp(x), _fp(y), _fp(out), len(x))
+    return out
+
+
+def sample_texture(texels, uv, flags=0):
+    """texture(sampler2D, uv) of one (h, w, 4) uint8 texture with sampler state `flags` at (n, 2) coordinates."""
+    from pathtracer_amd.scene import TextureDesc
+    t = np.ascontiguousarray(texels, np.uint8)
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    d = TextureDesc()
+    d.height, d.width, d.flags = t.shape[0], t.shape[1], flags
+    d.rgba8 = t.ctypes.data_as(C.POINTER(C.c_uint8))
+    out = np.empty((len(uv), 4), np.float32)
+    lib().orc_sample_texture(C.byref(d), _fp(uv), len(uv), _fp(out))
     return out
 
 

@@ -429,6 +429,33 @@ def test_textures_and_environment_map(backend, cornell, cameras):
     assert_same_frame(backend, o, rays)
 
 
+@pytest.mark.parametrize("flags", [1 | (1 << 2), 2 | (2 << 2), 1 | (2 << 2) | 16, 16])
+def test_texture_sampler_state(backend, cornell, cameras, flags):
+    """Wrap modes (clamp to edge, mirrored repeat) and the nearest filter of the scene's textures: same bits as
+    the oracle, and a picture that differs from the bilinear / repeat one."""
+    rng = np.random.default_rng(6)
+    tex0 = rng.integers(0, 256, (16, 32, 4), dtype=np.uint8)
+    tex1 = rng.integers(0, 256, (5, 3, 4), dtype=np.uint8)
+    verts = cornell.vertices.copy()
+    verts[:, 3:5] = verts[:, 0:2] * 3.7 - 0.4        # uv outside [0, 1] on most of the box
+    mats = cornell.materials.copy()
+    mats[0] = make_material(albedo=(1, 1, 1), roughness=1.0, albedo_map=0, mr_map=1, metallic=1.0)
+    mats[1] = make_material(albedo=(1, 0.5, 0.5), roughness=0.8, albedo_map=1)
+    sc = SceneData(verts, cornell.indices, cornell.submeshes, cornell.index_counts, cornell.xforms, mats, textures=[tex0, tex1])
+    o, rays = render_pair(backend, sc, cameras["96x64"], 96, 64, (1, 2), spp_per_frame=1, max_bounces=4)
+    plain = backend.read_accum()
+    sc.texture_flags = [flags, flags]
+    o, rays = render_pair(backend, sc, cameras["96x64"], 96, 64, (1, 2), spp_per_frame=1, max_bounces=4)
+    assert_same_frame(backend, o, rays)
+    assert not np.array_equal(backend.read_accum(), plain)
+    bad = SceneData(verts, cornell.indices, cornell.submeshes, cornell.index_counts, cornell.xforms, mats, textures=[tex0, tex1])
+    bad.texture_flags = [3, 0]
+    with pytest.raises(BackendError):
+        backend.scene_upload(bad)
+    backend.scene_upload(cornell)
+    backend.build_accel()
+
+
 def test_nan_pixels_are_red_like_the_oracle(backend, cornell, cameras):
     mats = cornell.materials.copy()
     mats[0] = make_material(emissive=(0, 0, 0), emissive_strength=np.inf)

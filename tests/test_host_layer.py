@@ -84,6 +84,21 @@ def test_gltf_import_synthetic(tmp_path):
     assert np.allclose(got.xforms[2].reshape(3, 4), [[0, 0, 1, 0.5], [0, 1, 0, 1], [-1, 0, 0, 1.5]], atol=1e-6)
 
 
+def test_gltf_sampler_state(tmp_path):
+    """wrapS / wrapT / magFilter of a glTF sampler end up as the PT_TEX_* flags of the image the texture points at."""
+    import json
+    path = write_gltf(tmp_path)
+    g = json.loads(open(path).read())
+    g["images"] = [{"uri": "a.png"}, {"uri": "b.png"}, {"uri": "c.png"}]
+    g["samplers"] = [{"wrapS": 33071, "wrapT": 33648, "magFilter": 9728}, {"wrapS": 33648}]
+    g["textures"] = [{"source": 1, "sampler": 0}, {"source": 0, "sampler": 1}, {"source": 2}, {"source": 1, "sampler": 1}]
+    g["materials"][0]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+    open(path, "w").write(json.dumps(g))
+    m = host.MeshSource(path)
+    assert m.texture_uris() == ["a.png", "b.png", "c.png"]
+    assert m.texture_samplers() == [2, 1 | (2 << 2) | 16, 0]      # image 1: the first texture that uses it decides
+
+
 def test_gltf_import_errors(tmp_path):
     with pytest.raises(RuntimeError):
         host.MeshSource(str(tmp_path / "missing.gltf"))

@@ -587,3 +587,37 @@ def test_preetham_sky_against_float64_restatement(params):
     scale = np.abs(want[upper]).max()
     assert np.isfinite(got[upper]).all()
     assert np.abs(got[upper] - want[upper]).max() < 2e-4 * scale
+
+
+@pytest.mark.parametrize("ws,wt,nearest", [(0, 0, 0), (1, 1, 0), (2, 2, 0), (1, 2, 0), (2, 0, 1), (0, 1, 1)])
+def test_texture_sampler_modes_against_the_vulkan_rules(ws, wt, nearest):
+    """Wrap modes and filters of texture(sampler2D, uv) against a float64 restatement of the Vulkan texel rules:
+    unnormalised coordinate u*w, bilinear taps at floor(x - 0.5) and the next texel (nearest: floor(x)), index i
+    wrapped as i mod w (repeat), clamp(i, 0, w-1) (clamp to edge), mirror((i mod 2w)) (mirrored repeat)."""
+    rng = np.random.default_rng(100 + ws + 4 * wt + 16 * nearest)
+    tex = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    uv = rng.uniform(-3, 3, (4000, 2)).astype(np.float32)
+    uv[:8] = [[0, 0], [1, 1], [-1, 2], [0.5, 0.5], [0.999999, 1e-7], [2, -2], [1.5, -0.5], [-0.0, 3]]
+    got = oracle_lib.sample_texture(tex, uv, ws | (wt << 2) | (16 if nearest else 0))
+    h, w = tex.shape[:2]
+
+    def wrap(i, n, mode):
+        if mode == 0:
+            return np.mod(i, n)
+        if mode == 1:
+            return np.clip(i, 0, n - 1)
+        m = np.mod(i, 2 * n)
+        return np.where(m < n, m, 2 * n - 1 - m)
+    t = tex.astype(np.float64) / 255.0
+    x, y = uv[:, 0].astype(np.float64) * w, uv[:, 1].astype(np.float64) * h
+    if nearest:
+        want = t[wrap(np.floor(y).astype(np.int64), h, wt), wrap(np.floor(x).astype(np.int64), w, ws)]
+        # a coordinate within rounding of a texel boundary may fall either side
+        ok = np.isclose(got, want, atol=1e-6).all(1) | (np.abs(x - np.round(x)) < 1e-4) | (np.abs(y - np.round(y)) < 1e-4)
+        assert ok.all()
+        return
+    x0, y0 = np.floor(x - 0.5).astype(np.int64), np.floor(y - 0.5).astype(np.int64)
+    fx, fy = (x - 0.5 - x0)[:, None], (y - 0.5 - y0)[:, None]
+    X0, X1, Y0, Y1 = wrap(x0, w, ws), wrap(x0 + 1, w, ws), wrap(y0, h, wt), wrap(y0 + 1, h, wt)
+    want = (t[Y0, X0] * (1 - fx) + t[Y0, X1] * fx) * (1 - fy) + (t[Y1, X0] * (1 - fx) + t[Y1, X1] * fx) * fy
+    assert np.abs(got - want).max() < 2e-5
