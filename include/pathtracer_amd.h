@@ -148,7 +148,11 @@ int pt_write_accum(pt_ctx* ctx, const float* rgba);
 int pt_resolve(pt_ctx* ctx);
 /* A submesh transform was edited and the acceleration structure is recreated (RayTracingLayer.cpp:569-604,
  * "Automatically update AS"): new per-submesh object-to-world matrices in the layout of pt_scene_desc.submesh_xforms,
- * then the hierarchy is rebuilt over the moved triangles (the reference too rebuilds, it does not refit). */
+ * then the hierarchy is rebuilt over the moved triangles, as the reference does.  With PT_UPDATE_REFIT in
+ * build_flags the hierarchy keeps its topology and only triangles, boxes and node grids are recomputed: several
+ * times faster than a rebuild and exact, but the hierarchy's quality decays as objects move far from where they
+ * were when it was built (stats->sah_cost tells). */
+#define PT_UPDATE_REFIT 0x100u
 int pt_update_transforms(pt_ctx* ctx, const float* submesh_xforms, uint32_t num_submeshes, uint32_t build_flags, pt_accel_stats* stats);
 /* PostProcessingPass (RayTracingLayer.cpp:286-318, PostProcessing.glsl:14-55): exposure (the reference's
  * default is 0.8, RayTracingLayer.h:92), ACES fit, gamma 2.2, stored as RGBA8 into an image the context owns

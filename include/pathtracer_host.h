@@ -62,6 +62,9 @@ const char* pth_layer_last_error(pth_layer* l);
 /* transform editor (RayTracingLayer.cpp:569-604, "Automatically update AS" on): new WorldTransform of a submesh as a
  * column-major mat4, acceleration structure recreated */
 int pth_layer_set_submesh_transform(pth_layer* l, uint32_t submesh, const float* column_major16);
+/* the same edit while the gizmo is being dragged: the hierarchy is refitted (topology kept, boxes recomputed), which
+ * is several times faster; finish the drag with pth_layer_set_submesh_transform to get a rebuilt hierarchy */
+int pth_layer_drag_submesh_transform(pth_layer* l, uint32_t submesh, const float* column_major16);
 /* TextureCube{path = "...hdr"} (RayTracingLayer.cpp:50-54): load a Radiance image and make it the environment */
 int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face_size);
 /* m_DoPostProcessing / m_Exposure (RayTracingLayer.h:90-92, RayTracingLayer.cpp:522-524); on by default, 0.8 */

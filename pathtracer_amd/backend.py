@@ -202,7 +202,7 @@ class Backend:
         return v.value
 
     def update_transforms(self, xforms, flags=0):
-        """New per-submesh 3x4 object-to-world matrices (n, 12); rebuilds the hierarchy."""
+        """New per-submesh 3x4 object-to-world matrices (n, 12); rebuilds the hierarchy, or refits it with flags=0x100 (PT_UPDATE_REFIT)."""
         x = np.ascontiguousarray(xforms, np.float32)
         st = AccelStats()
         self._check(self.lib.pt_update_transforms(self.h, _fp(x), x.size // 12, flags, C.byref(st)))

@@ -377,7 +377,7 @@ int pt_update_transforms(pt_ctx* ctx, const float* xforms, uint32_t num_submeshe
     PT_SYNC(ctx);
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_xforms, xforms, (size_t)num_submeshes * 48, hipMemcpyHostToDevice, ctx->stream));
     PT_SYNC(ctx);
-    int rc = build_accel(ctx, build_flags);
+    int rc = (build_flags & PT_UPDATE_REFIT) ? refit_accel(ctx) : build_accel(ctx, build_flags);
     if (stats) *stats = ctx->accel_stats;
     return rc;
 }

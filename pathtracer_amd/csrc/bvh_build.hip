@@ -49,22 +49,32 @@ __device__ __forceinline__ v3 xform_point(const float* __restrict__ m, v3 p)
               m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
 }
 
+// REFIT: tris already holds the records in leaf order and keeps that order; each one is recomputed from the
+// (submesh, prim) it names under the current transforms
+template <bool REFIT>
 __global__ void k_world_tris(uint32_t n, uint32_t ns, const uint32_t* __restrict__ sub_tri_offset,
                              const uint32_t* __restrict__ submeshes, const float* __restrict__ xforms,
                              const uint32_t* __restrict__ indices, const float* __restrict__ vertices,
-                             TriRec* __restrict__ tris, float4* __restrict__ tlo, float4* __restrict__ thi, int* bounds)
+                             TriRec* tris, float4* __restrict__ tlo, float4* __restrict__ thi, int* bounds)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     if (g < n) {
-        // submesh s with sub_tri_offset[s] <= g < sub_tri_offset[s+1]
-        uint32_t a = 0, b = ns;
-        while (b - a > 1) {
-            uint32_t m = (a + b) >> 1;
-            if (sub_tri_offset[m] <= g) a = m; else b = m;
+        uint32_t s, prim;
+        if (REFIT) {
+            s = tris[g].submesh;
+            prim = tris[g].prim;
+        } else {
+            // submesh s with sub_tri_offset[s] <= g < sub_tri_offset[s+1]
+            uint32_t a = 0, b = ns;
+            while (b - a > 1) {
+                uint32_t m = (a + b) >> 1;
+                if (sub_tri_offset[m] <= g) a = m; else b = m;
+            }
+            s = a;
+            prim = g - sub_tri_offset[s];
         }
-        uint32_t s = a, prim = g - sub_tri_offset[s];
         uint32_t vo = submeshes[s * 4 + 1], io = submeshes[s * 4 + 2];
         const float* m = xforms + s * 12;
         v3 w[3];
@@ -330,6 +340,49 @@ __device__ __forceinline__ uint32_t grid_exponent(float extent)
     return e > 253u ? 253u : e;                    // 255 steps of 2^126 span every finite extent; the inverse step stays normal
 }
 
+// the grid of a node: origin = lower corner of the padded union of its child boxes, one power-of-two step per axis
+struct NodeGrid { float lo[3]; uint32_t e[3]; float inv[3]; };
+
+__device__ __forceinline__ NodeGrid node_grid(const float4* clo, const float4* chi, int nc, float pad)
+{
+    NodeGrid g;
+    float hi3[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    g.lo[0] = g.lo[1] = g.lo[2] = __builtin_inff();
+    for (int k = 0; k < nc; k++) {
+        g.lo[0] = fminf(g.lo[0], clo[k].x - pad); g.lo[1] = fminf(g.lo[1], clo[k].y - pad); g.lo[2] = fminf(g.lo[2], clo[k].z - pad);
+        hi3[0] = fmaxf(hi3[0], chi[k].x + pad); hi3[1] = fmaxf(hi3[1], chi[k].y + pad); hi3[2] = fmaxf(hi3[2], chi[k].z + pad);
+    }
+    for (int a = 0; a < 3; a++) {
+        g.e[a] = grid_exponent(hi3[a] - g.lo[a]);
+        g.inv[a] = __uint_as_float((254u - g.e[a]) << 23);       // 2^-(e - 127), exact
+    }
+    return g;
+}
+
+// a child box, padded, on the node's grid: lower planes rounded down, upper planes up
+__device__ __forceinline__ void quantise_child(const NodeGrid& g, float4 lo, float4 hi, float pad, uint32_t* qlo, uint32_t* qhi)
+{
+    float l3[3] = {lo.x - pad, lo.y - pad, lo.z - pad}, h3[3] = {hi.x + pad, hi.y + pad, hi.z + pad};
+    for (int a = 0; a < 3; a++) {
+        // in double: the difference of two large floats must not overflow or round the wrong way
+        double ql = floor(((double)l3[a] - (double)g.lo[a]) * (double)g.inv[a]);
+        double qh = ceil(((double)h3[a] - (double)g.lo[a]) * (double)g.inv[a]);
+        qlo[a] = (uint32_t)fmin(fmax(ql, 0.0), 255.0);
+        qhi[a] = (uint32_t)fmin(fmax(qh, 0.0), 255.0);
+    }
+}
+
+// plane p of child k is byte (k & 3) of word p * 2 + (k >> 2)
+__device__ __forceinline__ void store_child_planes(Node8& nd, int k, const uint32_t* qlo, const uint32_t* qhi)
+{
+    uint32_t sh = (uint32_t)(k & 3) * 8u;
+    int wo = k >> 2;
+    for (int a = 0; a < 3; a++) {
+        nd.q[a * 2 + wo] |= qlo[a] << sh;
+        nd.q[(3 + a) * 2 + wo] |= qhi[a] << sh;
+    }
+}
+
 // one thread per frontier item: builds one Node8 and queues its internal children
 __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in, CollapseItem* __restrict__ out, uint32_t* out_count,
                            uint32_t* node_counter, uint32_t* leaf_counter, int n, const uint2* __restrict__ children,
@@ -382,22 +435,15 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
         }
 #endif
     }
-    // the node's grid: origin = lower corner of the padded union, one power-of-two step per axis
-    float lo3[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi3[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (int k = 0; k < nc; k++) {
-        float4 lo = b2lo[cand[k]], hi = b2hi[cand[k]];
-        lo3[0] = fminf(lo3[0], lo.x - pad); lo3[1] = fminf(lo3[1], lo.y - pad); lo3[2] = fminf(lo3[2], lo.z - pad);
-        hi3[0] = fmaxf(hi3[0], hi.x + pad); hi3[1] = fmaxf(hi3[1], hi.y + pad); hi3[2] = fmaxf(hi3[2], hi.z + pad);
-    }
-    uint32_t e3[3];
-    float inv3[3];
-    for (int a = 0; a < 3; a++) {
-        e3[a] = grid_exponent(hi3[a] - lo3[a]);
-        inv3[a] = __uint_as_float((254u - e3[a]) << 23);       // 2^-(e - 127), exact
+    NodeGrid gr;
+    {
+        float4 clo[8], chi[8];
+        for (int k = 0; k < nc; k++) { clo[k] = b2lo[cand[k]]; chi[k] = b2hi[cand[k]]; }
+        gr = node_grid(clo, chi, nc, pad);
     }
     Node8 nd;
-    nd.origin[0] = lo3[0]; nd.origin[1] = lo3[1]; nd.origin[2] = lo3[2];
-    nd.exps = e3[0] | (e3[1] << 8) | (e3[2] << 16);
+    nd.origin[0] = gr.lo[0]; nd.origin[1] = gr.lo[1]; nd.origin[2] = gr.lo[2];
+    nd.exps = gr.e[0] | (gr.e[1] << 8) | (gr.e[2] << 16);
     for (int w = 0; w < 12; w++) nd.q[w] = 0u;
     for (int w = 0; w < 8; w++) nd.pad[w] = 0u;
     uint32_t tstart = it.tstart;
@@ -409,14 +455,7 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
             uint32_t c = cand[k];
             float4 lo = b2lo[c], hi = b2hi[c];
             uint32_t cnt = __float_as_uint(lo.w);
-            float l3[3] = {lo.x - pad, lo.y - pad, lo.z - pad}, h3[3] = {hi.x + pad, hi.y + pad, hi.z + pad};
-            for (int a = 0; a < 3; a++) {
-                // in double: the difference of two large floats must not overflow or round the wrong way
-                double ql = floor(((double)l3[a] - (double)lo3[a]) * (double)inv3[a]);
-                double qh = ceil(((double)h3[a] - (double)lo3[a]) * (double)inv3[a]);
-                qlo[a] = (uint32_t)fmin(fmax(ql, 0.0), 255.0);
-                qhi[a] = (uint32_t)fmin(fmax(qh, 0.0), 255.0);
-            }
+            quantise_child(gr, lo, hi, pad, qlo, qhi);
             if (cnt <= PT_LEAF_MAX) {
                 nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
                 // write the subtree's triangles in depth-first order
@@ -443,15 +482,56 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
             }
             tstart += cnt;
         }
-        // plane p of child k is byte (k & 3) of word p * 2 + (k >> 2)
-        uint32_t sh = (uint32_t)(k & 3) * 8u;
-        int wo = k >> 2;
-        for (int a = 0; a < 3; a++) {
-            nd.q[a * 2 + wo] |= qlo[a] << sh;
-            nd.q[(3 + a) * 2 + wo] |= qhi[a] << sh;
-        }
+        store_child_planes(nd, k, qlo, qhi);
     }
     nodes[it.slot] = nd;
+}
+
+// Refit, one level at a time from the deepest up: one thread per node recomputes the node's grid and its quantised
+// child boxes from the children's current bounds (a leaf's from its triangles, an internal child's from nlo / nhi,
+// written when the level below was done) and records its own bounds.  Child references do not change.
+__global__ void k_refit_nodes(uint32_t first, uint32_t count, Node8* __restrict__ nodes, const float4* __restrict__ tlo,
+                              const float4* __restrict__ thi, float4* nlo, float4* nhi, float pad)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    Node8 nd = nodes[first + g];
+    float4 clo[8], chi[8];
+    int nc = 0;
+    float4 ulo = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f);
+    float4 uhi = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.0f);
+    for (int k = 0; k < 8; k++) {
+        uint32_t ch = nd.child[k];
+        if (ch == PT_CHILD_EMPTY) break;               // children fill the slots from 0
+        float4 lo, hi;
+        if (ch & PT_CHILD_LEAF) {
+            uint32_t t0 = ch & 0x0FFFFFFFu, cnt = ((ch >> 28) & 7u) + 1u;
+            lo = tlo[t0]; hi = thi[t0];
+            for (uint32_t j = 1; j < cnt; j++) {
+                float4 l = tlo[t0 + j], h = thi[t0 + j];
+                lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z);
+                hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
+            }
+        } else {
+            lo = nlo[ch]; hi = nhi[ch];
+        }
+        clo[nc] = lo; chi[nc] = hi;
+        nc++;
+        ulo.x = fminf(ulo.x, lo.x); ulo.y = fminf(ulo.y, lo.y); ulo.z = fminf(ulo.z, lo.z);
+        uhi.x = fmaxf(uhi.x, hi.x); uhi.y = fmaxf(uhi.y, hi.y); uhi.z = fmaxf(uhi.z, hi.z);
+    }
+    NodeGrid gr = node_grid(clo, chi, nc, pad);
+    nd.origin[0] = gr.lo[0]; nd.origin[1] = gr.lo[1]; nd.origin[2] = gr.lo[2];
+    nd.exps = gr.e[0] | (gr.e[1] << 8) | (gr.e[2] << 16);
+    for (int w = 0; w < 12; w++) nd.q[w] = 0u;
+    for (int k = 0; k < 8; k++) {
+        uint32_t qlo[3] = {255u, 255u, 255u}, qhi[3] = {0u, 0u, 0u};
+        if (k < nc) quantise_child(gr, clo[k], chi[k], pad, qlo, qhi);
+        store_child_planes(nd, k, qlo, qhi);
+    }
+    nodes[first + g] = nd;
+    nlo[first + g] = ulo;
+    nhi[first + g] = uhi;
 }
 
 // surface-area-heuristic cost: sum over nodes of area(child box)/area(root) * (1 for a node, count for a leaf)
@@ -487,6 +567,36 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
 };
+
+// scene bounds over the triangles that can be hit (read back from the ordered-int minima / maxima) and the padding
+// of every child box, which covers the rounding of the slab test and of the triangle test's t
+static int scene_extent(pt_ctx* ctx, int* d_bounds, float* lo, float* hi, float& pad)
+{
+    hipStream_t st = ctx->stream;
+    int hb[6];
+    PT_HIP(ctx, hipMemcpyAsync(hb, d_bounds, sizeof(hb), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    auto o2f = [](int i) { uint32_t u = (uint32_t)(i >= 0 ? i : i ^ 0x7fffffff); float f; memcpy(&f, &u, 4); return f; };
+    for (int k = 0; k < 3; k++) { lo[k] = o2f(hb[k]); hi[k] = o2f(hb[3 + k]); }
+    if (!(lo[0] <= hi[0])) {                      // no triangle has finite coordinates
+        for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0.0f;
+        PT_HIP(ctx, hipMemsetAsync(d_bounds, 0, 6 * sizeof(int), st));
+    }
+    float mc = 0.0f;
+    for (int k = 0; k < 3; k++) mc = fmaxf(mc, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+    // the quantised boxes and the slab test multiply extents by 1/direction: keep well inside the float range
+    if (!(mc <= 1.0e18f)) return set_error(ctx, PT_ERR_INVALID, "scene coordinates beyond +-1e18 are not supported");
+    float diag = sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    pad = fmaxf(diag, mc) * (1.0f / 262144.0f);
+    if (!(pad == pad) || pad > 3.0e38f) return set_error(ctx, PT_ERR_INVALID, "scene bounds are not finite");
+    return PT_OK;
+}
+
+static float padded_area(const float* lo, const float* hi, float pad)
+{
+    float ex = hi[0] - lo[0] + 2 * pad, ey = hi[1] - lo[1] + 2 * pad, ez = hi[2] - lo[2] + 2 * pad;
+    return ex * ey + ey * ez + ez * ex;
+}
 
 int build_accel(pt_ctx* ctx, uint32_t flags)
 {
@@ -540,22 +650,13 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     const int B = 256;
     uint32_t G = (n + B - 1) / B;
     k_init_bounds<<<1, 64, 0, st>>>(bounds.p);
-    k_world_tris<<<G, B, 0, st>>>(n, ctx->num_submeshes, ctx->d_sub_tri_offset, ctx->d_submeshes, ctx->d_xforms,
+    k_world_tris<false><<<G, B, 0, st>>>(n, ctx->num_submeshes, ctx->d_sub_tri_offset, ctx->d_submeshes, ctx->d_xforms,
                                   ctx->d_indices, ctx->d_vertices, tris_tmp.p, tlo.p, thi.p, bounds.p);
-    // scene bounds over the triangles that can be hit
-    int hb[6];
-    PT_HIP(ctx, hipMemcpyAsync(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost, st));
-    PT_HIP(ctx, hipStreamSynchronize(st));
-    auto o2f = [](int i) { uint32_t u = (uint32_t)(i >= 0 ? i : i ^ 0x7fffffff); float f; memcpy(&f, &u, 4); return f; };
-    float lo[3] = {o2f(hb[0]), o2f(hb[1]), o2f(hb[2])}, hi[3] = {o2f(hb[3]), o2f(hb[4]), o2f(hb[5])};
-    if (!(lo[0] <= hi[0])) {                      // no triangle has finite coordinates
-        for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0.0f;
-        PT_HIP(ctx, hipMemsetAsync(bounds.p, 0, 6 * sizeof(int), st));
+    float lo[3], hi[3], pad;
+    {
+        int rc = scene_extent(ctx, bounds.p, lo, hi, pad);
+        if (rc) return rc;
     }
-    float mc = 0.0f;
-    for (int k = 0; k < 3; k++) mc = fmaxf(mc, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
-    // the quantised boxes and the slab test multiply extents by 1/direction: keep well inside the float range
-    if (!(mc <= 1.0e18f)) return set_error(ctx, PT_ERR_INVALID, "scene coordinates beyond +-1e18 are not supported");
     k_morton<<<G, B, 0, st>>>(n, tlo.p, thi.p, bounds.p, keys.p, vals.p);
     size_t tmp_bytes = 0;
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
@@ -602,11 +703,6 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         root_id = n > 1 ? next_id - 1 : 0;   // the last node created is the root
     }
 
-    // padding of every child box: covers the rounding of the slab test and of the triangle test's t
-    float diag = sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-    float pad = fmaxf(diag, mc) * (1.0f / 262144.0f);
-    if (!(pad == pad) || pad > 3.0e38f) return set_error(ctx, PT_ERR_INVALID, "scene bounds are not finite");
-
     // collapse: counters[0] = nodes allocated, [1] = leaves, [2],[3] = frontier sizes (ping-pong)
     uint32_t init[4] = {1u, 0u, 0u, 0u};
     PT_HIP(ctx, hipMemcpyAsync(counters.p, init, sizeof(init), hipMemcpyHostToDevice, st));
@@ -614,8 +710,10 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, hipMemcpyAsync(fr[0].p, &root, sizeof(root), hipMemcpyHostToDevice, st));
     uint32_t nitems = 1, depth = 0;
     int cur = 0;
+    ctx->level_start.assign(1, 0u);        // nodes are numbered level by level: level d is [level_start[d], level_start[d + 1])
     while (nitems > 0) {
         depth++;
+        ctx->level_start.push_back(ctx->level_start.back() + nitems);
         PT_HIP(ctx, hipMemsetAsync(counters.p + 2 + (cur ^ 1), 0, sizeof(uint32_t), st));
         k_collapse<<<(nitems + 63) / 64, 64, 0, st>>>(nitems, fr[cur].p, fr[cur ^ 1].p, counters.p + 2 + (cur ^ 1), counters.p, counters.p + 1,
                                                      (int)n, children.p, b2lo.p, b2hi.p, vals_sorted.p, tris_tmp.p, ctx->d_tris, ctx->d_nodes, pad);
@@ -632,11 +730,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     stats.num_leaves = hc[1];
     stats.max_depth = depth;
 
-    float root_area;
-    {
-        float ex = hi[0] - lo[0] + 2 * pad, ey = hi[1] - lo[1] + 2 * pad, ez = hi[2] - lo[2] + 2 * pad;
-        root_area = ex * ey + ey * ez + ez * ex;
-    }
+    float root_area = padded_area(lo, hi, pad);
     PT_HIP(ctx, hipMemsetAsync(cost.p, 0, sizeof(float), st));
     if (root_area > 0.0f) k_sah<<<(ctx->num_nodes + B - 1) / B, B, 0, st>>>(ctx->num_nodes, ctx->d_nodes, root_area, cost.p);
     PT_HIP(ctx, hipMemcpyAsync(&stats.sah_cost, cost.p, sizeof(float), hipMemcpyDeviceToHost, st));
@@ -653,6 +747,55 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
                                                     std::to_string(PT_STACK_MAX) + " entries");
     ctx->stack_entries = depth ? ((7u * depth + 1u + 7u) & ~7u) : 8u;
     ctx->accel_built = true;
+    return PT_OK;
+}
+
+// The hierarchy keeps its topology (which triangles share a leaf, which children a node has); triangles, child
+// boxes and node grids follow the current transforms.  Exactly what a rebuild would write into the same topology.
+int refit_accel(pt_ctx* ctx)
+{
+    PT_SYNC(ctx);
+    if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "refit: no hierarchy has been built");
+    hipStream_t st = ctx->stream;
+    const uint32_t n = ctx->num_tris;
+    pt_accel_stats& stats = ctx->accel_stats;
+    if (n == 0) return PT_OK;
+    hipEvent_t e0, e1;
+    PT_HIP(ctx, hipEventCreate(&e0));
+    PT_HIP(ctx, hipEventCreate(&e1));
+    PT_HIP(ctx, hipEventRecord(e0, st));
+    DevBuf<float4> tlo, thi, nlo, nhi;
+    DevBuf<int> bounds;
+    DevBuf<float> cost;
+    PT_HIP(ctx, tlo.alloc(n));
+    PT_HIP(ctx, thi.alloc(n));
+    PT_HIP(ctx, nlo.alloc(ctx->num_nodes));
+    PT_HIP(ctx, nhi.alloc(ctx->num_nodes));
+    PT_HIP(ctx, bounds.alloc(6));
+    PT_HIP(ctx, cost.alloc(1));
+    const int B = 256;
+    k_init_bounds<<<1, 64, 0, st>>>(bounds.p);
+    k_world_tris<true><<<(n + B - 1) / B, B, 0, st>>>(n, ctx->num_submeshes, ctx->d_sub_tri_offset, ctx->d_submeshes, ctx->d_xforms,
+                                                     ctx->d_indices, ctx->d_vertices, ctx->d_tris, tlo.p, thi.p, bounds.p);
+    float lo[3], hi[3], pad;
+    {
+        int rc = scene_extent(ctx, bounds.p, lo, hi, pad);
+        if (rc) return rc;
+    }
+    for (size_t d = ctx->level_start.size() - 1; d-- > 0;) {
+        uint32_t first = ctx->level_start[d], count = ctx->level_start[d + 1] - first;
+        if (count) k_refit_nodes<<<(count + B - 1) / B, B, 0, st>>>(first, count, ctx->d_nodes, tlo.p, thi.p, nlo.p, nhi.p, pad);
+    }
+    float root_area = padded_area(lo, hi, pad);
+    PT_HIP(ctx, hipMemsetAsync(cost.p, 0, sizeof(float), st));
+    if (root_area > 0.0f) k_sah<<<(ctx->num_nodes + B - 1) / B, B, 0, st>>>(ctx->num_nodes, ctx->d_nodes, root_area, cost.p);
+    PT_HIP(ctx, hipMemcpyAsync(&stats.sah_cost, cost.p, sizeof(float), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipEventRecord(e1, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventElapsedTime(&stats.build_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return PT_OK;
 }
 

@@ -85,6 +85,7 @@ struct pt_ctx {
     size_t suspend_words = 0;
     uint2* d_spill = nullptr;       // traversal stack spill area, [chain][wave][entry][lane]
     size_t spill_entries = 0;       // allocated entries of d_spill
+    std::vector<uint32_t> level_start;  // node numbers at which the levels of the built hierarchy begin, and the node count
     uint32_t stack_entries = 64;    // stack entries a ray can need in the built hierarchy (7 per level + 1), a multiple of 8
     unsigned long long* d_wave_trace = nullptr;   // PT_WAVE_TRACE=<file>: per-wave timeline of the extend launches
     size_t wave_trace_len = 0;
@@ -111,6 +112,7 @@ struct pt_ctx {
 namespace ptd {
 int set_error(pt_ctx* ctx, int code, const std::string& msg);
 int build_accel(pt_ctx* ctx, uint32_t flags);
+int refit_accel(pt_ctx* ctx);
 int launch_trace(pt_ctx* ctx);     // launches the pending frames
 int launch_resolve(pt_ctx* ctx);
 int launch_postprocess(pt_ctx* ctx, float exposure);

@@ -17,7 +17,7 @@ EXPORTS = [
     "pth_layer_set_viewport", "pth_layer_set_params", "pth_layer_set_accumulate", "pth_layer_set_camera_position",
     "pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render", "pth_layer_frame_index",
     "pth_layer_read_image", "pth_layer_read_accum", "pth_layer_ray_count", "pth_layer_last_error",
-    "pth_layer_set_submesh_transform", "pth_layer_set_radiance_map", "pth_layer_set_post_processing", "pth_layer_read_postprocessed",
+    "pth_layer_set_submesh_transform", "pth_layer_drag_submesh_transform", "pth_layer_set_radiance_map", "pth_layer_set_post_processing", "pth_layer_read_postprocessed",
     "pth_hdr_load", "pth_pixels_free", "pth_ppm_write", "pth_image_load", "pth_image_free", "pth_mesh_load_textures",
 ]
 
@@ -72,6 +72,7 @@ def load_library():
     L.pth_layer_ray_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.pth_layer_last_error.argtypes = [vp]
     L.pth_layer_set_submesh_transform.argtypes = [vp, C.c_uint32, fp]
+    L.pth_layer_drag_submesh_transform.argtypes = [vp, C.c_uint32, fp]
     L.pth_layer_set_radiance_map.argtypes = [vp, C.c_char_p, C.c_uint32]
     L.pth_layer_set_post_processing.argtypes = [vp, C.c_int, C.c_float]
     L.pth_layer_read_postprocessed.argtypes = [vp, C.POINTER(C.c_uint8)]
@@ -241,10 +242,12 @@ class RayTracingLayer:
         self._check(self.L.pth_layer_ray_count(self.h, C.byref(v)))
         return v.value
 
-    def SetSubMeshTransform(self, submesh, matrix):
-        """matrix: 4x4 (row-major numpy) WorldTransform of the submesh; the acceleration structure is recreated."""
+    def SetSubMeshTransform(self, submesh, matrix, refit=False):
+        """matrix: 4x4 (row-major numpy) WorldTransform of the submesh; the acceleration structure is recreated
+        (refit=True: refitted, for an object that is being dragged)."""
         m = np.ascontiguousarray(np.asarray(matrix, np.float32).T.reshape(-1))
-        self._check(self.L.pth_layer_set_submesh_transform(self.h, submesh, _fp(m)))
+        fn = self.L.pth_layer_drag_submesh_transform if refit else self.L.pth_layer_set_submesh_transform
+        self._check(fn(self.h, submesh, _fp(m)))
 
     def SetRadianceMap(self, hdr_path, face_size=1024):
         self._check(self.L.pth_layer_set_radiance_map(self.h, os.fsencode(hdr_path), face_size))

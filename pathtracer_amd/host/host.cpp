@@ -253,7 +253,7 @@ void AccelerationStructure::UpdateMaterialData()
     m_Device->Check(pt_update_materials(m_Device->Get(), reinterpret_cast<const float*>(mats.data()), (uint32_t)mats.size()), "pt_update_materials");
 }
 
-void AccelerationStructure::UpdateTransforms()
+void AccelerationStructure::UpdateTransforms(bool refit)
 {
     std::vector<float> xforms;
     for (const SubMesh& s : m_Spec.Mesh->GetSubMeshes()) {
@@ -261,7 +261,7 @@ void AccelerationStructure::UpdateTransforms()
         for (int r = 0; r < 3; r++)
             for (int c = 0; c < 4; c++) xforms.push_back(w.at(r, c));
     }
-    m_Device->Check(pt_update_transforms(m_Device->Get(), xforms.data(), (uint32_t)(xforms.size() / 12), PT_BUILD_DEFAULT, nullptr), "pt_update_transforms");
+    m_Device->Check(pt_update_transforms(m_Device->Get(), xforms.data(), (uint32_t)(xforms.size() / 12), refit ? PT_UPDATE_REFIT : PT_BUILD_DEFAULT, nullptr), "pt_update_transforms");
 }
 
 // ---- RayTracingLayer ------------------------------------------------------------------------------
@@ -286,10 +286,10 @@ void RayTracingLayer::CreateAccelerationStructure()
     m_AccelerationStructure = CreateRef<AccelerationStructure>(m_Device, spec);
 }
 
-void RayTracingLayer::SetSubMeshTransform(uint32_t submesh, const Mat4& worldTransform)
+void RayTracingLayer::SetSubMeshTransform(uint32_t submesh, const Mat4& worldTransform, bool refit)
 {
     m_Mesh->GetSubMeshes().at(submesh).WorldTransform = worldTransform;
-    m_AccelerationStructure->UpdateTransforms();
+    m_AccelerationStructure->UpdateTransforms(refit);
 }
 
 void RayTracingLayer::SetViewportSize(uint32_t width, uint32_t height)

@@ -211,7 +211,7 @@ public:
     const std::vector<TextureData>& GetTextures() const { return m_Spec.Mesh->GetMeshSource()->GetTextures(); }
     const pt_accel_stats& GetStats() const { return m_Stats; }
     void UpdateMaterialData();
-    void UpdateTransforms();                                   // new instance transforms, hierarchy rebuilt                         // re-uploads the mesh's material buffers
+    void UpdateTransforms(bool refit = false);                                   // new instance transforms, hierarchy rebuilt                         // re-uploads the mesh's material buffers
 
 private:
     Ref<Device> m_Device;
@@ -250,7 +250,8 @@ public:
     void MaterialsChanged();                                   // RayTracingLayer.cpp:618-622
     // the transform editor of RayTracingLayer.cpp:569-604 with "Automatically update AS" on: new WorldTransform of a
     // submesh, acceleration structure recreated; like the reference it leaves FrameIndex alone
-    void SetSubMeshTransform(uint32_t submesh, const Mat4& worldTransform);
+    // refit: keep the hierarchy's topology (an object being dragged); otherwise the hierarchy is rebuilt, as the reference does
+    void SetSubMeshTransform(uint32_t submesh, const Mat4& worldTransform, bool refit = false);
     void SetRadianceMap(const std::string& hdrPath, uint32_t faceSize = 1024);   // RayTracingLayer.cpp:50-54 (TextureCube of the engine)
     void SetPostProcessing(bool on, float exposure) { m_DoPostProcessing = on; m_Exposure = exposure; }   // RayTracingLayer.cpp:522-524
     std::vector<uint8_t> ReadPostProcessed();                  // m_PostProcessingImage, RGBA8

@@ -184,6 +184,14 @@ int pth_layer_set_submesh_transform(pth_layer* l, uint32_t submesh, const float*
         l->layer->SetSubMeshTransform(submesh, m);
     });
 }
+int pth_layer_drag_submesh_transform(pth_layer* l, uint32_t submesh, const float* column_major16)
+{
+    return guarded(l, [&] {
+        ptamd::Mat4 m;
+        std::memcpy(&m, column_major16, sizeof(float) * 16);
+        l->layer->SetSubMeshTransform(submesh, m, true);
+    });
+}
 int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face_size)
 {
     return guarded(l, [&] { l->layer->SetRadianceMap(hdr_path, face_size); });

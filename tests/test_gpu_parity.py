@@ -647,6 +647,54 @@ def test_transform_edit_rebuilds_the_hierarchy(backend, cornell, cameras):
         backend.update_transforms(bad)
 
 
+UPDATE_REFIT = 0x100
+
+
+def test_transform_edit_with_refit(backend, cornell, cameras):
+    """PT_UPDATE_REFIT keeps the hierarchy's topology and recomputes triangles, boxes and node grids: refitting to
+    the transforms the hierarchy was built with gives back the same bytes; after a move the frames equal the
+    oracle's on the moved scene (the closest hit does not depend on the hierarchy), several edits in a row too;
+    and a rebuild afterwards is as good as new."""
+    import copy
+    W, H = 160, 120
+    backend.scene_upload(cornell)
+    st0 = backend.build_accel()
+    nodes0, tris0 = backend.debug_read_bvh()
+    st = backend.update_transforms(cornell.xforms, UPDATE_REFIT)
+    nodes1, tris1 = backend.debug_read_bvh()
+    assert np.array_equal(nodes0, nodes1) and np.array_equal(tris0, tris1)
+    assert (st.num_nodes, st.num_leaves, st.max_depth) == (st0.num_nodes, st0.num_leaves, st0.max_depth)
+    assert np.isclose(st.sah_cost, st0.sah_cost, rtol=1e-5)
+    x = np.array(cornell.xforms, np.float32).reshape(-1, 12).copy()
+    for step in range(3):
+        k = len(x) - 1 - step
+        m = x[k].reshape(3, 4)
+        m[:, 3] += np.array([0.03, 0.05 * (step + 1), -0.02], np.float32)
+        m[:, :3] *= np.float32(1.25 - 0.3 * step)
+        st = backend.update_transforms(x, UPDATE_REFIT)
+        assert st.num_nodes == st0.num_nodes
+        moved = copy.copy(cornell)
+        moved.xforms = x.copy()
+        o, rays = render_pair(backend, moved, cameras["512x512"], W, H, (1, 2), upload=False, spp_per_frame=1, max_bounces=4)
+        assert_same_frame(backend, o, rays)
+        rng = np.random.default_rng(40 + step)
+        r = random_rays(rng, 20000, [-0.35, -0.05, -0.6], [0.3, 0.6, 0.8])
+        hg, _ = backend.debug_intersect(r)
+        assert np.array_equal(hg, o.intersect(r, use_bvh=True))
+    refit_cost = st.sah_cost
+    st = backend.update_transforms(x)              # rebuild over the same transforms
+    assert st.sah_cost <= refit_cost * 1.0001
+    fresh = copy.copy(cornell)
+    fresh.xforms = x
+    backend.scene_upload(fresh)
+    st2 = backend.build_accel()
+    assert np.isclose(st.sah_cost, st2.sah_cost, rtol=1e-5)
+    backend.scene_upload(SceneData(cornell.vertices[:3], np.arange(3, dtype=np.uint32), [(0, 0, 0, 0)], [3],
+                                   cornell.xforms[:1], cornell.materials))
+    with pytest.raises(BackendError):
+        backend.update_transforms(cornell.xforms[:1], UPDATE_REFIT)        # nothing built yet for this scene
+
+
 def _soup(tris):
     """SceneData of independent triangles (n, 3, 3), one submesh, identity transform."""
     n = len(tris)

@@ -260,6 +260,14 @@ def test_layer_post_processing_and_radiance_map(tmp_path):
     layer.SetAccumulate(False)
     layer.OnUpdate(); layer.OnRender()
     assert not np.array_equal(layer.ReadImage(), before)
+    # dragging refits instead of rebuilding; the picture of a pose does not depend on how the hierarchy got there
+    rebuilt = layer.ReadImage()
+    move2 = move.copy()
+    move2[:3, 3] = (-0.3, 0.1, 0.2)
+    layer.SetSubMeshTransform(0, move2, refit=True)
+    layer.SetSubMeshTransform(0, move, refit=True)
+    layer.OnUpdate(); layer.OnRender()
+    assert np.array_equal(layer.ReadImage(), rebuilt)
     layer.SetAccumulate(True)
     # a dark red sky: frame index restarts, and the sky colour shows in the pixels that miss everything
     sky = np.zeros((16, 32, 3))
