@@ -135,6 +135,7 @@ int pt_set_params(pt_ctx* ctx, const pt_params* params);
  * launched together, when the batch is full or at the next call that reads, waits for or changes
  * what the queued frames use (every other entry point except pt_set_camera).  Frames are added to
  * the accumulation image in call order whatever the batching, so images do not depend on it.
+ * A launch error of a queued frame is returned by the call that launches it.
  * The caller sequences frame_index (1-based; 1 clears the accumulation image). */
 int pt_trace(pt_ctx* ctx, uint32_t frame_index);
 /* waits for the stream (the reference's Submit + FlushCommandBuffer, RayTracingLayer.cpp:317,424) */

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for pass in "$@"; do
   i=$((i+1))
-  timeout -s KILL 200 rocprofv3 --pmc $pass -d "$OUT/p$i" -o pmc -- python3 $ROOT/bench.py --steps 8 --warmup 2 --cpu-seconds 0 > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/p$i.log"; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc $pass -d "$OUT/p$i" -o pmc -- python3 $ROOT/bench.py --steps 8 --warmup 2 --cpu-seconds 0 ${BENCH_ARGS:-} > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/p$i.log"; exit 1; }
 done
 python3 - <<PY
 import sqlite3, glob
