@@ -345,7 +345,7 @@ def test_image_does_not_depend_on_ray_suspension(cornell, cameras, monkeypatch, 
 
 
 def test_cornell_512_config_and_golden_ids(backend, cornell, cameras):
-    # BASELINE configs[0]: Cornell 512x512, 1 spp, 4 bounces
+    # the CPU-runnable configuration: Cornell box 512x512, 1 spp, 4 bounces
     o, rays = render_pair(backend, cornell, cameras["512x512"], 512, 512, (1, 2), spp_per_frame=1, max_bounces=4)
     assert_same_frame(backend, o, rays)
     # 64x64 ids against the committed brute-force fixture
