@@ -561,6 +561,15 @@ __global__ void k_sah(uint32_t num_nodes, const Node8* __restrict__ nodes, float
     if ((threadIdx.x & 63) == 0 && c != 0.0f) atomicAdd(cost, c);
 }
 
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -613,9 +622,10 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     if (n == 0) { ctx->accel_built = true; return PT_OK; }
     if (n > 0x0FFFFFFFu) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^28-1 triangles");
 
-    hipEvent_t e0, e1;
-    PT_HIP(ctx, hipEventCreate(&e0));
-    PT_HIP(ctx, hipEventCreate(&e1));
+    EventPair ev;        // destroyed on every way out
+    PT_HIP(ctx, hipEventCreate(&ev.a));
+    PT_HIP(ctx, hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     PT_HIP(ctx, hipEventRecord(e0, st));
 
     DevBuf<TriRec> tris_tmp;
@@ -738,8 +748,6 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventElapsedTime(&stats.build_ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
 
     // a ray's stack holds at most 7 siblings per level and one entry more; the spill area is sized for that
     if (7u * depth + 1u > (uint32_t)PT_STACK_MAX)
@@ -760,9 +768,10 @@ int refit_accel(pt_ctx* ctx)
     const uint32_t n = ctx->num_tris;
     pt_accel_stats& stats = ctx->accel_stats;
     if (n == 0) return PT_OK;
-    hipEvent_t e0, e1;
-    PT_HIP(ctx, hipEventCreate(&e0));
-    PT_HIP(ctx, hipEventCreate(&e1));
+    EventPair ev;        // destroyed on every way out
+    PT_HIP(ctx, hipEventCreate(&ev.a));
+    PT_HIP(ctx, hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     PT_HIP(ctx, hipEventRecord(e0, st));
     DevBuf<float4> tlo, thi, nlo, nhi;
     DevBuf<int> bounds;
@@ -794,8 +803,6 @@ int refit_accel(pt_ctx* ctx)
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventElapsedTime(&stats.build_ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return PT_OK;
 }
 
