@@ -6,13 +6,19 @@
 //   k_shade    Miss.glsl:8-29, ClosestHit.glsl:144-226, RayGen.glsl:126-173, Disney.glsl:150-359
 //              sky on a miss, surface fetch, emission, BSDF sample, throughput, next ray,
 //              Russian roulette; finished paths either start the pixel's next sample or
-//              write the pixel (RayGen.glsl:347-372); survivors are compacted into the
+//              store the frame's colour of the pixel; survivors are compacted into the
 //              next queue with one ballot + one atomic per wave
-//   k_finish   adds the frame's queue sizes to the ray counter
+//   k_accumulate  RayGen.glsl:347-372  adds the finished frames to the accumulation image in frame
+//              order (frame 1 clears it), writes the running mean, NaN -> red
+//   k_finish   adds the batch's queue sizes to the ray counter
 //
-// A pixel owns one path at a time (the reference's samples of a pixel are sequential in the RNG
-// state, RayGen.glsl:314-345), so path state is indexed by pixel; rays and hits are indexed by
-// queue slot so that every round reads and writes them densely.
+// Up to PT_MAX_BATCH consecutive frames are traced by the same launches: a path is a (frame slot,
+// pixel) pair, with the slot's own frame index and camera (k_set_views).  A (slot, pixel) owns one
+// path at a time (the reference's samples of a pixel are sequential in the RNG state,
+// RayGen.glsl:314-345), so path state is indexed by slot * pixels + pixel; rays and hits are
+// indexed by queue slot so that every round reads and writes them densely.  A frame is also cut
+// into chains: independent pipelines of these kernels over disjoint pixel tiles and queue shards,
+// each on a stream of its own (launch_trace).
 //
 // The ray queue is cut into PT_SHARDS independent sub-queues.  8x8-pixel tile t starts in shard
 // t % PT_SHARDS, a workgroup with blockIdx % PT_SHARDS == s only ever reads and appends to shard s,
