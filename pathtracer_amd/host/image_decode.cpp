@@ -28,6 +28,8 @@ std::vector<uint8_t> read_file(const std::string& path)
     return d;
 }
 
+const size_t MAX_PIXELS = (size_t)1 << 26;     // a header claiming more is refused before anything is allocated
+
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 // ---- PNG ----------------------------------------------------------------------------------------------------
@@ -65,7 +67,7 @@ TextureData decode_png(const std::vector<uint8_t>& d)
         else if (!memcmp(type, "IEND", 4)) done = true;
         pos += 12 + (size_t)len;
     }
-    if (!have_ihdr || w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) throw std::runtime_error("png: bad size");
+    if (!have_ihdr || w == 0 || h == 0 || (uint64_t)w * h > MAX_PIXELS) throw std::runtime_error("png: bad size");
     if (interlace) throw std::runtime_error("png: interlaced images are not supported");
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
@@ -184,6 +186,15 @@ int decode_symbol(BitReader& br, const Huff& h)
 
 int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
 
+// a dequantised coefficient; corrupt streams can drive the DC predictor anywhere, so the product is formed in 64 bits
+// and kept inside the range the inverse transform's 64-bit intermediates are safe for
+int dequant(long v, int q)
+{
+    long x = v * q;
+    const long LIM = 1L << 24;
+    return (int)(x < -LIM ? -LIM : (x > LIM ? LIM : x));
+}
+
 const int ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                         35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
@@ -199,7 +210,7 @@ void idct8x8(const int* in /* dequantised, natural order */, uint8_t* out, int o
         const int* p = in + c;
         int* w = ws + c;
         if (!(p[8] | p[16] | p[24] | p[32] | p[40] | p[48] | p[56])) {
-            int dc = p[0] << PASS1_BITS;
+            int dc = p[0] * (1 << PASS1_BITS);
             for (int r = 0; r < 8; r++) w[r * 8] = dc;
             continue;
         }
@@ -207,7 +218,7 @@ void idct8x8(const int* in /* dequantised, natural order */, uint8_t* out, int o
         long z1 = (z2 + z3) * F_0_541;
         long tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
         z2 = p[0]; z3 = p[32];
-        long tmp0 = (z2 + z3) << CONST_BITS, tmp1 = (z2 - z3) << CONST_BITS;
+        long tmp0 = (z2 + z3) * (1L << CONST_BITS), tmp1 = (z2 - z3) * (1L << CONST_BITS);
         long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = p[56]; tmp1 = p[40]; tmp2 = p[24]; tmp3 = p[8];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
@@ -228,7 +239,7 @@ void idct8x8(const int* in /* dequantised, natural order */, uint8_t* out, int o
         long z2 = w[2], z3 = w[6];
         long z1 = (z2 + z3) * F_0_541;
         long tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
-        long tmp0 = ((long)w[0] + w[4]) << CONST_BITS, tmp1 = ((long)w[0] - w[4]) << CONST_BITS;
+        long tmp0 = ((long)w[0] + w[4]) * (1L << CONST_BITS), tmp1 = ((long)w[0] - w[4]) * (1L << CONST_BITS);
         long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
@@ -260,7 +271,7 @@ TextureData decode_jpeg(const std::vector<uint8_t>& d)
     for (;;) {
         if (pos + 4 > d.size()) throw std::runtime_error("jpeg: truncated before the scan");
         if (d[pos] != 0xFF) throw std::runtime_error("jpeg: marker expected");
-        while (pos < d.size() && d[pos + 1] == 0xFF) pos++;          // fill bytes
+        while (pos + 2 < d.size() && d[pos + 1] == 0xFF) pos++;      // fill bytes
         uint8_t m = d[pos + 1];
         pos += 2;
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
@@ -306,6 +317,7 @@ TextureData decode_jpeg(const std::vector<uint8_t>& d)
             height = (s[1] << 8) | s[2]; width = (s[3] << 8) | s[4];
             int nc = s[5];
             if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc || width == 0 || height == 0) throw std::runtime_error("jpeg: unsupported component count or size");
+            if ((size_t)width * (size_t)height > MAX_PIXELS) throw std::runtime_error("jpeg: image larger than 2^26 pixels");
             comp.resize((size_t)nc);
             for (int i = 0; i < nc; i++) {
                 comp[i].id = s[6 + 3 * i]; comp[i].h = s[7 + 3 * i] >> 4; comp[i].v = s[7 + 3 * i] & 15; comp[i].tq = s[8 + 3 * i];
@@ -354,7 +366,9 @@ TextureData decode_jpeg(const std::vector<uint8_t>& d)
                                 int tdc = decode_symbol(br, hdc[c.td]);
                                 if (tdc > 11) throw std::runtime_error("jpeg: bad DC size");
                                 c.pred += extend(br.bits(tdc), tdc);
-                                blk[0] = c.pred * qt[c.tq][0];
+                                if (c.pred > (1 << 20)) c.pred = 1 << 20;
+                                if (c.pred < -(1 << 20)) c.pred = -(1 << 20);
+                                blk[0] = dequant(c.pred, qt[c.tq][0]);
                                 for (int k = 1; k < 64;) {
                                     int rs = decode_symbol(br, hac[c.ta]);
                                     int r = rs >> 4, sz = rs & 15;
@@ -364,7 +378,7 @@ TextureData decode_jpeg(const std::vector<uint8_t>& d)
                                     }
                                     k += r;
                                     if (k > 63) throw std::runtime_error("jpeg: coefficient index out of range");
-                                    blk[ZIGZAG[k]] = extend(br.bits(sz), sz) * qt[c.tq][ZIGZAG[k]];
+                                    blk[ZIGZAG[k]] = dequant(extend(br.bits(sz), sz), qt[c.tq][ZIGZAG[k]]);
                                     k++;
                                 }
                                 idct8x8(blk, &c.plane[(size_t)((my * c.v + by) * 8) * c.bw + (size_t)(mx * c.h + bx) * 8], c.bw);

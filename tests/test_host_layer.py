@@ -388,3 +388,39 @@ def test_reference_textures_decode_like_pillow():
         got = host.load_image(f).astype(np.int32)
         want = np.asarray(Image.open(f).convert("RGBA")).astype(np.int32)
         assert got.shape == want.shape and np.abs(got - want).max() <= 1, f
+
+
+def test_parsers_survive_mutated_files(tmp_path):
+    """tests/fuzz_parsers.cpp, built with the address and undefined-behaviour sanitizers, over corrupted copies of small
+    PNG / JPEG / .hdr / glTF files: every input is either parsed or refused with an exception."""
+    import shutil
+    import subprocess
+    from tests import hdr_py
+    Image = pytest.importorskip("PIL.Image")
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hostdir = os.path.join(root, "pathtracer_amd", "host")
+    exe = str(tmp_path / "fuzz_parsers")
+    cmd = ["g++", "-O1", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", hostdir,
+           "-I", os.path.join(root, "include"), "-o", exe, os.path.join(root, "tests", "fuzz_parsers.cpp")]
+    cmd += [os.path.join(hostdir, f) for f in ("gltf.cpp", "image_io.cpp", "image_decode.cpp")] + ["-lz"]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and "sanitize" in built.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert built.returncode == 0, built.stderr[-2000:]
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (24, 20, 3), dtype=np.uint8)
+    files = []
+    for name, img, kw in (("a.png", Image.fromarray(a), {}), ("b.png", Image.fromarray(np.dstack([a, a[..., :1]])), {}),
+                          ("c.png", Image.fromarray(a[..., 0]), {}), ("d.png", Image.fromarray(a).convert("P"), {}),
+                          ("a.jpg", Image.fromarray(a), {"quality": 80, "subsampling": 0}),
+                          ("b.jpg", Image.fromarray(a), {"quality": 60, "subsampling": 2}), ("c.jpg", Image.fromarray(a[..., 0]), {})):
+        img.save(tmp_path / name, **kw)
+        files.append(str(tmp_path / name))
+    hdr_py.write_hdr(tmp_path / "a.hdr", hdr_py.float_to_rgbe(rng.uniform(0, 4, (16, 32, 3))))
+    files += [str(tmp_path / "a.hdr"), write_gltf(tmp_path)]
+    env = dict(os.environ, ITERS="400", SEED="7", ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
+    run = subprocess.run([exe, str(tmp_path)] + files, capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
+    assert "parsed" in run.stdout
