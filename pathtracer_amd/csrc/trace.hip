@@ -160,9 +160,10 @@ static constexpr uint32_t DEFERRED = 0xFFFFFFFEu;
 // rayD.w (as bits): rounds the path is behind schedule in the low byte, RAY_RESUMES if the ray continues a suspended traversal
 static constexpr uint32_t RAY_LAG_MASK = 0xFFu, RAY_RESUMES = 0x100u;
 
-// 5 waves per SIMD need at most 96 VGPRs
+// 4 waves per SIMD: 128 VGPRs, no scratch; the LDS stack would admit 4.5, and 5 (96 VGPRs) measured no faster on a
+// mid-sized scene and slower on a large one, whose traversal competes for cache rather than for issue slots
 #ifndef PT_EXT_WAVES_PER_SIMD
-#define PT_EXT_WAVES_PER_SIMD 5
+#define PT_EXT_WAVES_PER_SIMD 4
 #endif
 #define PT_EXT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES_PER_SIMD, PT_EXT_WAVES_PER_SIMD)))
 
