@@ -406,6 +406,17 @@ def test_full_disney_procedural_scene(backend):
     assert len(np.unique(backend.read_primary_ids()[..., 0])) > 20 and np.isfinite(img).all()
 
 
+def test_benchmark_workload_at_full_size(backend):
+    """The configuration bench.py times: the full Sponza-class scene (273 536 triangles, full-Disney materials) at
+    1920x1080, 8 bounces, frames issued back to back in one batch: ray count, primary ids and every pixel's bits
+    equal the oracle's (24 M ray segments, about two seconds of the host's cores)."""
+    sc = procedural.sponza_class()
+    W, H = 1920, 1080
+    o, rays = render_pair(backend, sc, procedural.sponza_camera(W, H), W, H, (1, 2, 3), spp_per_frame=1, max_bounces=8)
+    assert rays > 30_000_000
+    assert_same_frame(backend, o, rays)
+
+
 def test_russian_roulette_option(backend, cornell, cameras):
     o, rays = render_pair(backend, cornell, cameras["96x64"], 96, 64, (1, 2), spp_per_frame=2, max_bounces=12, rr_depth=2)
     assert_same_frame(backend, o, rays)
