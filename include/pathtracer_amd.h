@@ -175,12 +175,13 @@ int pt_read_env(pt_ctx* ctx, float* rgba, uint32_t* face_size);
 int pt_read_primary_ids(pt_ctx* ctx, uint32_t* submesh_prim_pairs);
 /* number of traceRayEXT-equivalents issued since the context was created */
 int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
-/* A frame is traced as `chains` (1, 2, 4 or 8) independent pipelines, each with a share of the
+/* A frame is traced as `chains` (1, 2, 4, 8 or 16) independent pipelines, each with a share of the
  * pixel tiles and a HIP stream of its own, so that the tail of one pipeline's traversal launch
  * overlaps the others' work; images do not depend on the setting.  Chains overlap only if HIP has
- * a hardware queue for each: the default is 4, or 8 when GPU_MAX_HW_QUEUES >= 8 is in the
- * environment (HIP reads it when its runtime starts).  No counterpart in the reference, whose
- * scheduling is the Vulkan driver's. */
+ * a hardware queue for each: the default is 4, or 8 / 16 when GPU_MAX_HW_QUEUES >= 8 / >= 16 is in
+ * the environment (HIP reads it when its runtime starts; 16 is the measured optimum, more queues
+ * than chains cost throughput).  No counterpart in the reference, whose scheduling is the Vulkan
+ * driver's. */
 int pt_set_chains(pt_ctx* ctx, uint32_t chains);
 /* Up to `frames` (1..4) consecutive pt_trace calls share their kernel launches: the paths of all
  * of them fill one set of ray queues, so a launch has that many times the rays to hide its tail

@@ -199,7 +199,7 @@ int pt_create(int device_ordinal, pt_ctx** out)
     // GPU_MAX_HW_QUEUES (read when the runtime starts) says otherwise.
     uint32_t hwq = 4;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = (uint32_t)atoi(e);
-    ctx->chains = hwq >= 8 ? 8u : 4u;
+    ctx->chains = hwq >= 16 ? 16u : (hwq >= 8 ? 8u : 4u);
     if (const char* e = getenv("PT_DEFER")) { int v = atoi(e); ctx->defer_rounds = v < 0 ? 0u : (v > 8 ? 8u : (uint32_t)v); }
     if (const char* e = getenv("PT_CHAINS")) {
         uint32_t c = (uint32_t)atoi(e);
@@ -455,7 +455,7 @@ int pt_set_chains(pt_ctx* ctx, uint32_t chains)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (chains < 1 || chains > PT_MAX_CHAINS || PT_SHARDS % chains)
-        return set_error(ctx, PT_ERR_INVALID, "pt_set_chains: chains must be 1, 2, 4 or 8");
+        return set_error(ctx, PT_ERR_INVALID, "pt_set_chains: chains must be 1, 2, 4, 8 or 16");
     PT_SYNC(ctx);
     {
         int rc = finish_timing(ctx);

@@ -30,7 +30,7 @@ struct alignas(128) Node8 {
 #endif
 #define PT_SHARDS 32u     // independent sub-queues of the wavefront ray queue (multiple of the 8 XCDs)
 #ifndef PT_MAX_CHAINS
-#define PT_MAX_CHAINS 8     // independent pipelines a frame can be split into (a divisor of PT_SHARDS)
+#define PT_MAX_CHAINS 16    // independent pipelines a frame can be split into (a divisor of PT_SHARDS)
 #endif
 
 // world-space triangle, 48 bytes, in leaf order: (v0, submesh) (v1, prim) (v2, 0)

@@ -647,7 +647,10 @@ int launch_trace(pt_ctx* ctx)
         if (per_shard > cap_per_shard) per_shard = cap_per_shard;
         return per_shard * spc;
     };
-    static const uint32_t ext_waves_per_cu = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 40u;
+    // traversal waves per CU over all chains: enough for every chain's launch to fill its share of the chip, few enough
+    // for a wave to refill its lanes several times (measured optimum 40 for 8 chains, 48 for 16)
+    static const uint32_t waves_override = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 0u;
+    const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? 48u : 40u);
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
     uint32_t sh_blocks = chain_grid(SHADE_BLOCK, max_blocks, nframes);

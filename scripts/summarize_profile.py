@@ -49,7 +49,7 @@ try:
               "concurrency %.2f; rocprofv3 average of k_extend<false, true> over the whole run: %.4f ms"
               % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], prod[1] / prod[0] * 1e-3 if prod else float("nan")),
               "", "Kernel tracing costs throughput here: the profiler's per-dispatch bookkeeping keeps fewer launches in flight at a time "
-              "(concurrency above, against about 5 without the profiler), so each launch shares the chip with fewer others and is shorter "
+              "(concurrency above, against roughly twice as many without the profiler), so each launch shares the chip with fewer others and is shorter "
               "than in an unprofiled run, where bench.py reports a higher value and a longer avg_launch_ms.  Compare the two numbers of this "
               "run with each other."]
 except (OSError, IndexError, KeyError, ValueError):

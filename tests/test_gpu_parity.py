@@ -260,11 +260,11 @@ def test_cornell_frames_bit_exact(backend, cornell, cameras, W, H, S, B, frames)
     assert_same_frame(backend, o, rays)
 
 
-@pytest.mark.parametrize("chains", [1, 2, 8])
+@pytest.mark.parametrize("chains", [1, 2, 8, 16])
 def test_image_does_not_depend_on_the_chain_count(backend, cornell, cameras, chains):
-    """Frames issued back to back (no synchronisation between them) with the frame split into 1, 2 or 8
+    """Frames issued back to back (no synchronisation between them) with the frame split into 1, 2, 8 or 16
     independent pipelines: same bits as the oracle, hence as each other.  72x40 leaves some shards of the
-    ray queue without a tile, 8 chains then have empty pipelines."""
+    ray queue without a tile, 8 and 16 chains then have empty pipelines."""
     try:
         backend.set_chains(chains)
         for W, H in ((72, 40), (256, 256)):
