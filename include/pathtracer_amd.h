@@ -183,10 +183,10 @@ int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
  * than chains cost throughput).  No counterpart in the reference, whose scheduling is the Vulkan
  * driver's. */
 int pt_set_chains(pt_ctx* ctx, uint32_t chains);
-/* Up to `frames` (1..4) consecutive pt_trace calls share their kernel launches: the paths of all
+/* Up to `frames` (1..8) consecutive pt_trace calls share their kernel launches: the paths of all
  * of them fill one set of ray queues, so a launch has that many times the rays to hide its tail
  * behind.  1 launches every frame at its pt_trace call (lowest latency for an interactive viewer
- * that displays every frame); the default, 4, is the throughput setting for progressive
+ * that displays every frame); the default, 8, is the throughput setting for progressive
  * accumulation.  No counterpart in the reference, which records one vkCmdTraceRaysKHR per frame. */
 int pt_set_batch(pt_ctx* ctx, uint32_t frames);
 /* mode 1: every kernel launch of later pt_trace calls is bracketed by HIP events on the stream

@@ -236,7 +236,7 @@ class Backend:
         self._check(self.lib.pt_set_chains(self.h, int(chains)))
 
     def set_batch(self, frames):
-        """Consecutive trace() calls (1..4) that share their kernel launches; images do not depend on it."""
+        """Consecutive trace() calls (1..8) that share their kernel launches; images do not depend on it."""
         self._check(self.lib.pt_set_batch(self.h, int(frames)))
 
     def set_profiling(self, mode):

@@ -386,7 +386,7 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (width == 0 || height == 0) return set_error(ctx, PT_ERR_INVALID, "pt_resize: empty image");
-    if ((uint64_t)width * height > (1ull << 28) / PT_MAX_BATCH) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_resize: more than 2^26 pixels");
+    if ((uint64_t)width * height > (1ull << 28) / PT_MAX_BATCH) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_resize: more than 2^25 pixels");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_SYNC(ctx);
     free_images(ctx);
@@ -469,7 +469,7 @@ int pt_set_chains(pt_ctx* ctx, uint32_t chains)
 int pt_set_batch(pt_ctx* ctx, uint32_t frames)
 {
     if (!ctx) return PT_ERR_INVALID;
-    if (frames < 1 || frames > PT_MAX_BATCH) return set_error(ctx, PT_ERR_INVALID, "pt_set_batch: frames must be 1..4");
+    if (frames < 1 || frames > PT_MAX_BATCH) return set_error(ctx, PT_ERR_INVALID, "pt_set_batch: frames must be 1..8");
     if (!ctx->pending.empty()) {
         int rc = launch_trace(ctx);
         if (rc) return rc;

@@ -41,7 +41,7 @@ struct alignas(16) TriRec {
 };
 
 #ifndef PT_MAX_BATCH
-#define PT_MAX_BATCH 4      // frames traced together: consecutive pt_trace calls share their launches
+#define PT_MAX_BATCH 8      // frames traced together: consecutive pt_trace calls share their launches
 #endif
 
 // what differs between the frames of a batch

@@ -283,9 +283,9 @@ def test_image_does_not_depend_on_the_chain_count(backend, cornell, cameras, cha
         backend.set_chains(3)
 
 
-@pytest.mark.parametrize("batch", [1, 2, 3, 4])
+@pytest.mark.parametrize("batch", [1, 2, 3, 4, 8])
 def test_image_does_not_depend_on_frame_batching(backend, cornell, cameras, batch):
-    """Up to four consecutive trace() calls share their launches.  Seven frames issued with no synchronisation in
+    """Up to eight consecutive trace() calls share their launches.  Ten frames issued with no synchronisation in
     between, the camera and (once) the parameters changing from frame to frame, so that short batches are launched
     while full ones are still running: same bits as the oracle tracing them one by one."""
     def moved(cam, k):
@@ -303,7 +303,7 @@ def test_image_does_not_depend_on_frame_batching(backend, cornell, cameras, batc
             backend.set_params(p)
             r0 = backend.ray_count()
             calls = []
-            for n, f in enumerate((1, 2, 3, 1, 2, 3, 4)):     # the fourth call restarts the accumulation inside a batch
+            for n, f in enumerate((1, 2, 3, 1, 2, 3, 4, 5, 6, 7)):     # the fourth call restarts the accumulation inside a batch
                 if n == 5:
                     p = Params.reference(spp_per_frame=1, max_bounces=3)
                     backend.set_params(p)
@@ -324,9 +324,9 @@ def test_image_does_not_depend_on_frame_batching(backend, cornell, cameras, batc
             assert np.array_equal(bits(got_accum), bits(o.read_accum()))
             assert np.array_equal(bits(got_image), bits(o.read_image()))
     finally:
-        backend.set_batch(4)
+        backend.set_batch(8)
     with pytest.raises(BackendError):
-        backend.set_batch(5)
+        backend.set_batch(9)
 
 
 @pytest.mark.parametrize("defer", ["0", "1", "4"])
