@@ -32,7 +32,7 @@ static void free_scene(pt_ctx* c)
     (void)dev_free(c->d_vertices); (void)dev_free(c->d_indices); (void)dev_free(c->d_submeshes);
     (void)dev_free(c->d_xforms); (void)dev_free(c->d_materials); (void)dev_free(c->d_tex_pool);
     (void)dev_free(c->d_tex_table); (void)dev_free(c->d_env); (void)dev_free(c->d_sub_tri_offset);
-    (void)dev_free(c->d_nodes); (void)dev_free(c->d_tris);
+    (void)dev_free(c->d_nodes); (void)dev_free(c->d_tris); (void)dev_free(c->d_shade_tris);
     c->scene_loaded = false;
     c->accel_built = false;
 }

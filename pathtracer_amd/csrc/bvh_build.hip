@@ -534,6 +534,27 @@ __global__ void k_refit_nodes(uint32_t first, uint32_t count, Node8* __restrict_
     nhi[first + g] = uhi;
 }
 
+// the shading record of every triangle, in leaf order (see ShadeTri)
+__global__ void k_shade_tris(uint32_t n, const TriRec* __restrict__ tris, const uint32_t* __restrict__ submeshes,
+                             const uint32_t* __restrict__ indices, const float* __restrict__ vertices, ShadeTri* __restrict__ out)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t s = tris[g].submesh, prim = tris[g].prim;
+    const uint32_t vo = submeshes[s * 4 + 1], io = submeshes[s * 4 + 2];
+    ShadeTri r;
+    for (int k = 0; k < 3; k++) {
+        const float* v = vertices + (size_t)(indices[io + prim * 3 + k] + vo) * 12;
+        r.uv[k][0] = v[3]; r.uv[k][1] = v[4];
+        r.n[k][0] = v[5]; r.n[k][1] = v[6]; r.n[k][2] = v[7];
+    }
+    r.material = submeshes[s * 4 + 3];
+    r.submesh = s;
+    r.prim = prim;
+    r.pad[0] = r.pad[1] = 0u;
+    out[g] = r;
+}
+
 // surface-area-heuristic cost: sum over nodes of area(child box)/area(root) * (1 for a node, count for a leaf)
 __global__ void k_sah(uint32_t num_nodes, const Node8* __restrict__ nodes, float root_area, float* cost)
 {
@@ -614,6 +635,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     uint32_t n = ctx->num_tris;
     if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
     if (ctx->d_tris) { (void)hipFree(ctx->d_tris); ctx->d_tris = nullptr; }
+    if (ctx->d_shade_tris) { (void)hipFree(ctx->d_shade_tris); ctx->d_shade_tris = nullptr; }
     ctx->accel_built = false;
     ctx->num_nodes = 0;
     pt_accel_stats& stats = ctx->accel_stats;
@@ -656,6 +678,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, cost.alloc(1));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, (size_t)n * sizeof(Node8)));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_tris, (size_t)n * sizeof(TriRec)));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_shade_tris, (size_t)n * sizeof(ShadeTri)));
 
     const int B = 256;
     uint32_t G = (n + B - 1) / B;
@@ -732,6 +755,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         cur ^= 1;
         if (depth > 4096) return set_error(ctx, PT_ERR_BVH_DEPTH, "hierarchy collapse did not terminate");
     }
+    k_shade_tris<<<G, B, 0, st>>>(n, ctx->d_tris, ctx->d_submeshes, ctx->d_indices, ctx->d_vertices, ctx->d_shade_tris);
     uint32_t hc[2];
     PT_HIP(ctx, hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipStreamSynchronize(st));

@@ -51,6 +51,7 @@ struct pt_ctx {
     // hierarchy
     ptd::Node8* d_nodes = nullptr;
     ptd::TriRec* d_tris = nullptr;
+    ptd::ShadeTri* d_shade_tris = nullptr;   // per triangle in leaf order, see ShadeTri
     uint32_t num_nodes = 0;
     bool accel_built = false;
     pt_accel_stats accel_stats{};

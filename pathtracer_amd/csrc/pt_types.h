@@ -61,6 +61,17 @@ struct TraceParams {
 };
 
 // scene tables as uploaded (reference layouts) + build products
+// What shading needs of a triangle, gathered once at build time in leaf order (the order of TriRec): the three
+// vertices' texture coordinates and object-space normals, the material, and the ids.  One 80-byte read in place of
+// the chain triangle -> submesh record -> three indices -> three vertices.
+struct ShadeTri {
+    float uv[3][2];
+    float n[3][3];
+    uint32_t material, submesh, prim;
+    uint32_t pad[2];
+};
+static_assert(sizeof(ShadeTri) == 80, "ShadeTri is five 16-byte words");
+
 struct SceneView {
     const float* vertices;      // 12 floats per vertex
     const uint32_t* indices;
@@ -74,6 +85,7 @@ struct SceneView {
     uint32_t num_tris;
     const Node8* nodes;
     const TriRec* tris;
+    const ShadeTri* shade_tris;
 };
 
 } // namespace ptd

@@ -344,23 +344,19 @@ PT_DEV v3 sample_env(const SceneView& sc, v3 d)
 }
 
 // ClosestHit.glsl:144-226: what the payload needs downstream
-PT_DEV void fetch_surface(const SceneView& sc, uint32_t submesh, uint32_t prim, float hu, float hv, v3 rayDir,
+PT_DEV void fetch_surface(const SceneView& sc, const ShadeTri& st, float hu, float hv, v3 rayDir,
                           Surf& s, v3& emission, v3& worldNormal)
 {
-    const uint32_t* sm = sc.submeshes + submesh * 4;
-    uint32_t vertexOffset = sm[1], indexOffset = sm[2], materialIndex = sm[3];
-    const float* M = sc.materials + (size_t)materialIndex * 22;
-    const float* o2w = sc.xforms + submesh * 12;
+    const float* M = sc.materials + (size_t)st.material * 22;
+    const float* o2w = sc.xforms + st.submesh * 12;
 
     float bary[3] = {1.0f - hu - hv, hu, hv};
     float uvx = 0.0f, uvy = 0.0f;
     v3 nrm = V3(0.0f);
     for (int i = 0; i < 3; i++) {
-        uint32_t idx = sc.indices[prim * 3 + i + indexOffset] + vertexOffset;
-        const float* v = sc.vertices + (size_t)idx * 12;
-        uvx += v[3] * bary[i];
-        uvy += v[4] * bary[i];
-        nrm = nrm + V3(v[5], v[6], v[7]) * bary[i];
+        uvx += st.uv[i][0] * bary[i];
+        uvy += st.uv[i][1] * bary[i];
+        nrm = nrm + V3(st.n[i][0], st.n[i][1], st.n[i][2]) * bary[i];
     }
     nrm = normalize(nrm);
     // mat3(gl_ObjectToWorldEXT) * normal -- not the inverse transpose (ClosestHit.glsl:170)
@@ -469,12 +465,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
                 rad = rad + sky * thr;
                 done = true;
             } else {
-                const TriRec* tr = sc.tris + tri;
-                uint32_t submesh = tr->submesh, prim = tr->prim;
-                if (bounce == 0 && sample == 0 && pixel / npix + 1u == P.nframes) q.primary[pixel % npix] = make_uint2(submesh, prim);
+                ShadeTri st;
+                {
+                    const uint4* rec = reinterpret_cast<const uint4*>(sc.shade_tris + tri);
+                    uint4* dst = reinterpret_cast<uint4*>(&st);
+                    for (int w = 0; w < 5; w++) dst[w] = rec[w];
+                }
+                if (bounce == 0 && sample == 0 && pixel / npix + 1u == P.nframes) q.primary[pixel % npix] = make_uint2(st.submesh, st.prim);
                 Surf s;
                 v3 emission, N;
-                fetch_surface(sc, submesh, prim, h.y, h.z, d, s, emission, N);
+                fetch_surface(sc, st, h.y, h.z, d, s, emission, N);
                 rad = rad + emission * thr;                           // RayGen.glsl:137
                 bool last_bounce = bounce + 1 >= P.max_bounces;
                 if (last_bounce && sample + 1 >= P.spp) {
@@ -578,6 +578,7 @@ SceneView scene_view(const pt_ctx* ctx)
     sv.num_tris = ctx->num_tris;
     sv.nodes = ctx->d_nodes;
     sv.tris = ctx->d_tris;
+    sv.shade_tris = ctx->d_shade_tris;
     return sv;
 }
 
