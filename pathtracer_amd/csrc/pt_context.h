@@ -69,9 +69,9 @@ struct pt_ctx {
     float4* d_rayO[2] = {nullptr, nullptr};
     float4* d_rayD[2] = {nullptr, nullptr};
     float4* d_hits = nullptr;
-    float4* d_stA = nullptr;
-    float4* d_stB = nullptr;
-    float4* d_stC = nullptr;
+    float4* d_stA[2] = {nullptr, nullptr};     // path state travels with the ray: per queue slot (throughput, seed)
+    float4* d_stB[2] = {nullptr, nullptr};     // and (radiance, bounce | sample << 16)
+    float4* d_stC = nullptr;                   // per path: colour of the pixel's finished samples
     float4* d_partial = nullptr;    // finished colour per (frame slot, pixel)
     ptd::FrameView* d_views = nullptr;   // per chain PT_MAX_BATCH frame views, written on the chain's stream
     // frames handed to pt_trace and not launched yet: up to `batch` of them share their launches (more rays per launch).

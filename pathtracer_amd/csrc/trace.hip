@@ -42,7 +42,9 @@ struct Queues {
     float4* rayO_in; float4* rayD_in;
     float4* rayO_out; float4* rayD_out;
     float4* hits;
-    float4* stA; float4* stB; float4* stC;
+    float4* stA_in; float4* stB_in;     // path state of the queued rays, by queue slot like the rays
+    float4* stA_out; float4* stB_out;
+    float4* stC;                        // per path
     uint32_t* counts;       // of this chain: counts[r * nshards + ls] = rays queued in its shard ls for round r
     uint32_t shard0, nshards;   // the chain owns shards [shard0, shard0 + nshards)
     uint32_t shard_cap;     // slots per shard; shard s owns slots [s * shard_cap, (s + 1) * shard_cap)
@@ -137,18 +139,19 @@ __global__ void __launch_bounds__(256) k_raygen(TraceParams P, Queues q)
         uint32_t x = 0, y = 0;
         bool valid = cs < nslots && slot_to_pixel(slot, P.width, P.height, x, y);
         v3 o = V3(0.0f), d = V3(0.0f);
-        uint32_t path = 0;
+        uint32_t path = 0, seed0 = 0;
         if (valid) {
             uint32_t pixel = x + y * P.width;
             path = k * npix + pixel;
             const FrameView& V = q.views[k];
             uint32_t seed = pixel * V.frame;           // RayGen.glsl:314-315
             camera_ray(P, V, x, y, 0, seed, o, d);
-            q.stA[path] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
-            q.stB[path] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
+            seed0 = seed;
         }
         uint32_t out = (q.shard0 + ls) * q.shard_cap + wave_append(valid, &q.counts[ls]);
         if (valid) {
+            q.stA_out[out] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed0));
+            q.stB_out[out] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(path));
             q.rayD_out[out] = make_float4(d.x, d.y, d.z, 0.0f);
         }
@@ -182,6 +185,8 @@ struct ExtendArgs {
     uint32_t* susp_out;         // records for the next round
     const float4* rayO; const float4* rayD;
     float4* next_rayO; float4* next_rayD;
+    const float4* stA; const float4* stB;       // path state by queue slot: a suspended ray takes its state along
+    float4* next_stA; float4* next_stB;
     float4* hits;
     uint2* spill;
 };
@@ -221,6 +226,8 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
         float4 ro = a.rayO[base + i], rd = a.rayD[base + i];
         a.next_rayO[base + slot] = ro;
         a.next_rayD[base + slot] = make_float4(rd.x, rd.y, rd.z, u2f(((f2u(rd.w) & RAY_LAG_MASK) + 1u) | RAY_RESUMES));
+        a.next_stA[base + slot] = a.stA[base + i];
+        a.next_stB[base + slot] = a.stB[base + i];
         a.hits[base + i] = make_float4(0.0f, 0.0f, 0.0f, u2f(DEFERRED));
         trav_save(s, a.susp_out + ((size_t)ls * a.susp_cap + slot) * a.susp_words, lds_stack, stride, ovf);
     };
@@ -445,6 +452,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
         v3 o = V3(0.0f), d = V3(0.0f);
         uint32_t pixel = 0;            // the path: frame slot * pixels + pixel
         float lag_bits = 0.0f;
+        float4 outA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), outB = outA;
         if (valid && f2u(q.hits[slot].w) == DEFERRED) valid = false;     // suspended: the traversal kernel has queued it for the next round
         if (valid) {
             float4 ro = q.rayO_in[slot], rd = q.rayD_in[slot], h = q.hits[slot];
@@ -452,7 +460,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
             pixel = f2u(ro.w);
             o = V3(ro.x, ro.y, ro.z);
             d = V3(rd.x, rd.y, rd.z);
-            float4 A = q.stA[pixel], B = q.stB[pixel];
+            float4 A = q.stA_in[slot], B = q.stB_in[slot];
             v3 thr = V3(A.x, A.y, A.z), rad = V3(B.x, B.y, B.z);
             uint32_t seed = f2u(A.w);
             uint32_t bs = f2u(B.w);
@@ -520,12 +528,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
                 alive = true;
             }
             if (alive) {
-                q.stA[pixel] = make_float4(thr.x, thr.y, thr.z, u2f(seed));
-                q.stB[pixel] = make_float4(rad.x, rad.y, rad.z, u2f(bounce | (sample << 16)));
+                outA = make_float4(thr.x, thr.y, thr.z, u2f(seed));
+                outB = make_float4(rad.x, rad.y, rad.z, u2f(bounce | (sample << 16)));
             }
         }
         uint32_t out = shard * q.shard_cap + wave_append(alive, &q.counts[(round + 1) * q.nshards + ls]);
         if (alive) {
+            q.stA_out[out] = outA;
+            q.stB_out[out] = outB;
             q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
             q.rayD_out[out] = make_float4(d.x, d.y, d.z, lag_bits);
         }
@@ -711,7 +721,7 @@ int launch_trace(pt_ctx* ctx)
         PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
         Queues q;
         q.hits = ctx->d_hits;
-        q.stA = ctx->d_stA; q.stB = ctx->d_stB; q.stC = ctx->d_stC;
+        q.stC = ctx->d_stC;
         q.counts = counts;
         q.shard0 = c * spc; q.nshards = spc;
         q.shard_cap = ctx->shard_cap;
@@ -726,6 +736,8 @@ int launch_trace(pt_ctx* ctx)
         {
             q.rayO_in = q.rayO_out = ctx->d_rayO[0];
             q.rayD_in = q.rayD_out = ctx->d_rayD[0];
+            q.stA_in = q.stA_out = ctx->d_stA[0];
+            q.stB_in = q.stB_out = ctx->d_stB[0];
             uint32_t blocks = ((tiles / chains + spc) * nframes * 64u + 255u) / 256u;
             if (blocks > max_blocks) blocks = max_blocks;
             k_raygen<<<blocks, 256, 0, st>>>(P, q);
@@ -747,6 +759,8 @@ int launch_trace(pt_ctx* ctx)
             ea.shard0 = q.shard0; ea.nshards = spc; ea.shard_cap = ctx->shard_cap;
             ea.rayO = ctx->d_rayO[in]; ea.rayD = ctx->d_rayD[in];
             ea.next_rayO = ctx->d_rayO[out]; ea.next_rayD = ctx->d_rayD[out];
+            ea.stA = ctx->d_stA[in]; ea.stB = ctx->d_stB[in];
+            ea.next_stA = ctx->d_stA[out]; ea.next_stB = ctx->d_stB[out];
             ea.hits = ctx->d_hits;
             ea.spill = spill;
             unsigned long long* wt = wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr;
@@ -757,6 +771,8 @@ int launch_trace(pt_ctx* ctx)
             PT_HIP(ctx, mark());
             q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
             q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
+            q.stA_in = ctx->d_stA[in]; q.stB_in = ctx->d_stB[in];
+            q.stA_out = ctx->d_stA[out]; q.stB_out = ctx->d_stB[out];
             k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
             PT_HIP(ctx, mark());
         }
