@@ -15,8 +15,10 @@
 // Up to PT_MAX_BATCH consecutive frames are traced by the same launches: a path is a (frame slot,
 // pixel) pair, with the slot's own frame index and camera (k_set_views).  A (slot, pixel) owns one
 // path at a time (the reference's samples of a pixel are sequential in the RNG state,
-// RayGen.glsl:314-345), so path state is indexed by slot * pixels + pixel; rays and hits are
-// indexed by queue slot so that every round reads and writes them densely.  A frame is also cut
+// RayGen.glsl:314-345), numbered slot * pixels + pixel.  Rays, hits and the path's running state
+// (throughput, seed, radiance, bounce and sample counters) are indexed by queue slot, so that every
+// round reads and writes them densely; only the colour of a pixel's finished samples and the
+// frame's finished colour are kept per path.  A frame is also cut
 // into chains: independent pipelines of these kernels over disjoint pixel tiles and queue shards,
 // each on a stream of its own (launch_trace).
 //
