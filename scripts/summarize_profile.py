@@ -45,7 +45,7 @@ try:
     bench = [json.loads(l) for l in open(os.path.join(src, "trace.log")) if l.startswith('{"metric"')][-1]
     rl = bench["roofline"]
     prod = agg.get("ptd::k_extend<false, true>")
-    lines += ["", "bench.py inside this run: value %.1f %s, roofline.avg_launch_ms %.4f (HIP events, %d launches of the timing window), "
+    lines += ["", "bench.py inside this run: value %.1f %s, roofline.avg_launch_ms %.4f (device clock inside the kernel, %d launches of the timing window), "
               "concurrency %.2f; rocprofv3 average of k_extend<false, true> over the whole run: %.4f ms"
               % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], prod[1] / prod[0] * 1e-3 if prod else float("nan")),
               "", "Kernel tracing costs throughput here: the profiler's per-dispatch bookkeeping keeps fewer launches in flight at a time "
