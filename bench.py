@@ -14,8 +14,7 @@ Also reported on the same JSON line:
                128 B per hierarchy node visited, 48 B per triangle tested; counted by the kernel's own
                counting variant) against the 8 TB/s HBM peak.  A frame runs as `chains` pipelines side by
                side, so `concurrency` launches of the kernel share the chip at a time: avg_launch_ms is the
-               average duration of one launch (first wave's start to last wave's end on the device clock, taken by
-               the kernel itself in profiling mode; what rocprofv3 reports as the kernel's duration),
+               average duration of one launch (HIP events on the stream it runs on; what rocprofv3 reports),
                achieved = alg_bytes_per_launch / avg_launch_ms * concurrency = all launches' bytes / the
                time during which at least one of them was running
   cpu_baseline the CPU oracle (a port of the reference shaders, not the reference itself) on the
@@ -159,7 +158,7 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: timed pass (device-clock span per launch), then a counting pass ----
+        # ---- roofline of the dominant kernel: timed pass (HIP events per launch), then a counting pass ----
         # profiled frames run back to back like the timed ones; the read-out covers all of them
         nprof = min(16, args.steps)
         b.set_profiling(1)

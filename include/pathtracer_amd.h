@@ -85,10 +85,8 @@ typedef struct pt_accel_stats {
     float sah_cost;            /* surface-area-heuristic cost of the built hierarchy */
 } pt_accel_stats;
 
-/* per-kernel device time of the frames traced since the previous read-out: HIP events on the
- * streams the kernels run on; a traversal launch is timed by its own waves instead (first wave's
- * start to last wave's end on the device clock), which leaves out its wait in the hardware
- * queue.  A frame runs as several chains side by side (pt_set_chains) and
+/* per-kernel device time of the frames traced since the previous read-out (HIP events on the
+ * streams the kernels run on).  A frame runs as several chains side by side (pt_set_chains) and
  * consecutive frames overlap, so launches of one kernel overlap: raygen_ms / extend_ms / shade_ms
  * are sums of the launch durations, extend_busy_ms is the time during which at least one
  * traversal launch was running, total_ms is first start to last end. */

@@ -72,18 +72,14 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
             // the frame's queue sizes tell which rounds had work
             uint64_t queued = 0;
             for (uint32_t k = 0; k < spc; k++) queued += slot.h_counts[c * chain_words + (size_t)r * spc + k];
-            float sh = 0.0f;
+            float e = 0.0f, sh = 0.0f;
+            PT_HIP(ctx, hipEventElapsedTime(&e, ev[1 + 2 * r], ev[2 + 2 * r]));
             PT_HIP(ctx, hipEventElapsedTime(&sh, ev[2 + 2 * r], ev[3 + 2 * r]));
-            // the traversal launch is timed by its own waves (first start, last end on the device's 100 MHz clock): the
-            // span a kernel trace reports, without the wait in the queue that stream events would add to it
-            unsigned long long tm[2];
-            memcpy(tm, slot.h_counts + c * chain_words + pt_chain_time_offset(R, spc) + (size_t)4 * r, sizeof tm);
-            if (queued > 0 && tm[1] != 0) {
-                const unsigned long long start = ~tm[0], end = tm[1];
-                if (ctx->ext_spans.empty() && t.extend_launches == 0) ctx->clock_ref = start;
-                const float b0 = (float)((double)(long long)(start - ctx->clock_ref) * 1e-5), e = (float)((double)(end - start) * 1e-5);
+            if (queued > 0) {
                 t.extend_ms += e; t.shade_ms += sh;
                 t.extend_launches++; t.shade_launches++;
+                float b0 = 0.0f;
+                PT_HIP(ctx, hipEventElapsedTime(&b0, ctx->prof_ref, ev[1 + 2 * r]));
                 ctx->ext_spans.push_back({b0, b0 + e});
             }
             t.rays += queued;
@@ -505,7 +501,7 @@ int pt_trace(pt_ctx* ctx, uint32_t frame_index)
     if (rounds + 1 > ctx->counts_cap) {
         PT_SYNC(ctx);
         (void)dev_free(ctx->d_counts);
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, pt_counts_words(rounds) * sizeof(uint32_t)));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_counts, pt_chain_words(rounds, PT_SHARDS) * sizeof(uint32_t)));
         ctx->counts_cap = rounds + 1;
     }
     FrameView v;

@@ -87,7 +87,6 @@ struct pt_ctx {
     uint2* d_spill = nullptr;       // traversal stack spill area, [chain][wave][entry][lane]
     size_t spill_entries = 0;       // allocated entries of d_spill
     std::vector<uint32_t> level_start;  // node numbers at which the levels of the built hierarchy begin, and the node count
-    unsigned long long clock_ref = 0;   // device clock reading the timing window's traversal spans are relative to
     uint32_t stack_entries = 64;    // stack entries a ray can need in the built hierarchy (7 per level + 1), a multiple of 8
     unsigned long long* d_wave_trace = nullptr;   // PT_WAVE_TRACE=<file>: per-wave timeline of the extend launches
     size_t wave_trace_len = 0;
@@ -131,12 +130,8 @@ SceneView scene_view(const pt_ctx* ctx);
 } // namespace ptd
 
 // words of one chain's counter block: rounds + 1 rows of queue sizes, as many of fetch cursors, one row whose first
-// word counts the deferred rays; then, 8-byte aligned, per round the traversal launch's own clock readings
-// (two 64-bit words: ~first wave's start and last wave's end, both kept with atomicMax; filled when timing is on)
-inline size_t pt_chain_time_offset(uint32_t rounds, uint32_t shards_per_chain) { return ((((size_t)2 * (rounds + 1) + 1) * shards_per_chain) + 1) & ~(size_t)1; }
-inline size_t pt_chain_words(uint32_t rounds, uint32_t shards_per_chain) { return pt_chain_time_offset(rounds, shards_per_chain) + (size_t)4 * rounds; }
-// enough for any number of chains
-inline size_t pt_counts_words(uint32_t rounds) { return pt_chain_words(rounds, 1) * PT_SHARDS; }
+// word counts the deferred rays
+inline size_t pt_chain_words(uint32_t rounds, uint32_t shards_per_chain) { return ((size_t)2 * (rounds + 1) + 1) * shards_per_chain; }
 
 #define PT_SYNC(ctx)                                                                              \
     do {                                                                                          \

@@ -191,7 +191,6 @@ struct ExtendArgs {
     float4* next_stA; float4* next_stB;
     float4* hits;
     uint2* spill;
-    unsigned long long* times;      // {~start, end} of this launch on the device clock, or nullptr
 };
 
 template <bool STATS, bool CUT>
@@ -199,7 +198,6 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     __shared__ uint16_t owner[PT_OWNER_BYTES / 2];
-    if (a.times && threadIdx.x == 0) atomicMax(&a.times[0], ~wall_clock64());
     const uint32_t ls = blockIdx.x % a.nshards;
     const uint32_t n = a.counts[ls];
     const uint32_t base = (a.shard0 + ls) * a.shard_cap;
@@ -238,7 +236,6 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
     auto resume_record = [&](uint32_t i) { return a.susp_in + ((size_t)ls * a.susp_cap + i) * a.susp_words; };
     trace_wave<STATS, CUT>(sc.nodes, sc.tris, sc.num_tris, n, &a.cursors[ls], stack + threadIdx.x, EXT_BLOCK,
                            a.spill + (size_t)blockIdx.x * (a.stack_entries * 64) + threadIdx.x, owner, fetch, emit, suspend, resume_record, sn, st, STATS ? &ws : nullptr);
-    if (a.times && threadIdx.x == 0) atomicMax(&a.times[1], wall_clock64());
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
@@ -768,7 +765,6 @@ int launch_trace(pt_ctx* ctx)
             ea.next_stA = ctx->d_stA[out]; ea.next_stB = ctx->d_stB[out];
             ea.hits = ctx->d_hits;
             ea.spill = spill;
-            ea.times = prof ? reinterpret_cast<unsigned long long*>(counts + pt_chain_time_offset(rounds, spc)) + 2 * r : nullptr;
             unsigned long long* wt = wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr;
             if (counting && ea.next_counts) k_extend<true, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
             else if (counting) k_extend<true, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);

@@ -45,9 +45,21 @@ try:
     bench = [json.loads(l) for l in open(os.path.join(src, "trace.log")) if l.startswith('{"metric"')][-1]
     rl = bench["roofline"]
     prod = agg.get("ptd::k_extend<false, true>")
-    lines += ["", "bench.py inside this run: value %.1f %s, roofline.avg_launch_ms %.4f (device clock inside the kernel, %d launches of the timing window), "
-              "concurrency %.2f; rocprofv3 average of k_extend<false, true> over the whole run: %.4f ms"
-              % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], prod[1] / prod[0] * 1e-3 if prod else float("nan")),
+    # the same launches bench.py timed: the plain traversal launches just before the counting pass (k_extend<true, ...>) begins
+    window_avg = float("nan")
+    try:
+        disp = db.execute("select S.display_name, K.start, K.end from rocpd_kernel_dispatch K join rocpd_info_kernel_symbol S "
+                          "on S.id = K.kernel_id and S.guid = K.guid where S.display_name like '%k_extend<%' order by K.start").fetchall()
+        first_counting = min((st for name, st, en in disp if "k_extend<true" in name), default=None)
+        plain = [(st, en) for name, st, en in disp if "k_extend<false" in name and (first_counting is None or st < first_counting)]
+        win = plain[-int(rl["launches"]):]
+        if win:
+            window_avg = sum(en - st for st, en in win) / len(win) * 1e-6
+    except sqlite3.Error:
+        pass
+    lines += ["", "bench.py inside this run: value %.1f %s, roofline.avg_launch_ms %.4f (HIP events on the launch's stream, %d launches of the timing window), "
+              "concurrency %.2f; rocprofv3's average duration of those same launches: %.4f ms (of k_extend<false, true> over the whole run: %.4f ms)"
+              % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], window_avg, prod[1] / prod[0] * 1e-3 if prod else float("nan")),
               "", "Kernel tracing costs throughput here: the profiler's per-dispatch bookkeeping keeps fewer launches in flight at a time "
               "(concurrency above, against roughly twice as many without the profiler), so each launch shares the chip with fewer others and is shorter "
               "than in an unprofiled run, where bench.py reports a higher value and a longer avg_launch_ms.  Compare the two numbers of this "
