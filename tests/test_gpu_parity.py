@@ -417,6 +417,16 @@ def test_benchmark_workload_at_full_size(backend):
     assert_same_frame(backend, o, rays)
 
 
+def test_large_scene(backend):
+    """The Bistro-class street: 2.97 M triangles, an 11-level hierarchy that outgrows every cache, long grazing rays
+    (the longest traversals suspend and spill).  Ray count, primary ids and every pixel's bits equal the oracle's."""
+    sc = procedural.bistro_class()
+    W, H = 320, 180
+    o, rays = render_pair(backend, sc, procedural.bistro_camera(W, H), W, H, (1, 2, 3), spp_per_frame=1, max_bounces=8)
+    assert backend.accel.num_triangles > 2_900_000 and backend.accel.max_depth >= 10
+    assert_same_frame(backend, o, rays)
+
+
 def test_russian_roulette_option(backend, cornell, cameras):
     o, rays = render_pair(backend, cornell, cameras["96x64"], 96, 64, (1, 2), spp_per_frame=2, max_bounces=12, rr_depth=2)
     assert_same_frame(backend, o, rays)
