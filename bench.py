@@ -92,7 +92,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
-    # rehearsal on a one-GPU box: PT_BENCH_REHEARSE=1 puts every rank on GPU 0 and reduces through gloo
+    # rehearsal on a one-GPU box: PT_BENCH_REHEARSE=1 puts every rank on GPU 0 and reduces through gloo (host-staged:
+    # RCCL refuses two ranks on one device)
     rehearse = os.environ.get("PT_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -141,12 +142,12 @@ def main():
     if world > 1:
         ptdist.merge_accumulation(r.accum)
         if rank == 0:
-            b.resolve()
+            r.resolve()         # waits for the reduce on the device (pt_wait_stream), then pt_resolve
     barrier()
     dt = time.perf_counter() - t0
 
     rays = b.ray_count() - rays0
-    stat = torch.tensor([dt, float(rays)], dtype=torch.float64, device=device)
+    stat = torch.tensor([dt, float(rays)], dtype=torch.float64, device="cpu" if rehearse else device)
     if world > 1:
         tmax = stat[0:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -199,6 +199,11 @@ int pt_last_trace_timing(pt_ctx* ctx, pt_trace_timing* out);
 /* the context's main HIP stream (hipStream_t as void*).  Work the caller enqueues on it after this
  * call runs after every pt_trace issued so far, and later pt_trace calls run after that work. */
 void* pt_stream(pt_ctx* ctx);
+/* The opposite direction: everything the context does after this call (pt_trace, pt_resolve, pt_postprocess,
+ * read-backs) runs after the work enqueued so far on `stream` (a hipStream_t as void*; NULL = the null stream),
+ * without blocking the host.  For callers that write the bound images on a stream of their own, e.g. a collective
+ * (RCCL reduce of the accumulation image, multi-GPU merge) followed by pt_resolve. */
+int pt_wait_stream(pt_ctx* ctx, void* stream);
 /* device pointers of the images currently rendered into */
 void* pt_device_image(pt_ctx* ctx);
 void* pt_device_accum(pt_ctx* ctx);

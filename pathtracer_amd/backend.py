@@ -18,7 +18,7 @@ EXPORTS = [
     "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
     "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
-    "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_device_image", "pt_device_accum",
+    "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_wait_stream", "pt_device_image", "pt_device_accum",
     "pt_debug_intersect", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
 ]
 
@@ -89,6 +89,7 @@ def load_library():
     for name in ("pt_stream", "pt_device_image", "pt_device_accum", "pt_device_postprocessed"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
+    lib.pt_wait_stream.argtypes = [vp, vp]
     lib.pt_debug_intersect.argtypes = [vp, fp, C.c_uint32, up, C.POINTER(C.c_uint64)]
     lib.pt_debug_math.argtypes = [vp, C.c_int, fp, fp, fp, C.c_uint32]
     lib.pt_debug_disney_sample.argtypes = [vp, C.c_uint32, fp, fp, fp, up, fp, fp, fp]
@@ -250,6 +251,10 @@ class Backend:
 
     def stream(self):
         return self.lib.pt_stream(self.h)
+
+    def wait_stream(self, stream):
+        """Later work of the context runs after what is enqueued so far on `stream` (hipStream_t as int; 0 = null stream)."""
+        self._check(self.lib.pt_wait_stream(self.h, C.c_void_p(stream)))
 
     def device_image(self):
         return self.lib.pt_device_image(self.h)

@@ -243,6 +243,7 @@ void pt_destroy(pt_ctx* ctx)
         if (ctx->chain_stream[c]) (void)hipStreamDestroy(ctx->chain_stream[c]);
     }
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -635,6 +636,18 @@ void* pt_stream(pt_ctx* ctx)
     if (join_chains(ctx) != PT_OK) return nullptr;
     ctx->main_dirty = true;
     return (void*)ctx->stream;
+}
+int pt_wait_stream(pt_ctx* ctx, void* stream)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = join_chains(ctx);          // queued frames are launched first: they were recorded before this call
+    if (rc) return rc;
+    if (!ctx->wait_event) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming));
+    PT_HIP(ctx, hipEventRecord(ctx->wait_event, (hipStream_t)stream));
+    PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->wait_event, 0));
+    ctx->main_dirty = true;             // the other chains are ordered after the main stream at the next launch
+    return PT_OK;
 }
 void* pt_device_image(pt_ctx* ctx) { return ctx ? (void*)ctx->d_image : nullptr; }
 void* pt_device_accum(pt_ctx* ctx) { return ctx ? (void*)ctx->d_accum : nullptr; }

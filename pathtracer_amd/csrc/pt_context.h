@@ -31,6 +31,7 @@ struct pt_ctx {
     hipStream_t chain_stream[PT_MAX_CHAINS] = {};
     hipEvent_t chain_done[PT_MAX_CHAINS] = {};
     hipEvent_t fork_event = nullptr;
+    hipEvent_t wait_event = nullptr;   // pt_wait_stream: marks the caller's stream
     bool main_dirty = true;      // the main stream got work the other chains have not yet been ordered after
     bool join_pending = false;   // the other chains got work the main stream has not yet been ordered after
 

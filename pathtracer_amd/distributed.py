@@ -19,9 +19,17 @@ def stripe(rank, world_size, frames_per_rank, first_frame=2):
 
 
 def merge_accumulation(accum: torch.Tensor, dst=0, group=None):
-    """Sums every rank's accumulation image (rgb sums and the sample count in .w) onto `dst`."""
+    """Sums every rank's accumulation image (rgb sums and the sample count in .w) onto `dst`, in place.
+    With RCCL the reduce is enqueued on torch's current stream order: device work that reads `accum`
+    afterwards on another stream must wait for that stream (GpuRenderer.resolve does).  A gloo group
+    (CPU tests, one-GPU rehearsals) reduces host memory, so a device tensor is staged through the host."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if accum.is_cuda and dist.get_backend(group) == "gloo":
+            host = accum.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum
 
 
@@ -70,9 +78,10 @@ class GpuRenderer:
 
     def load_accum(self, tensor):
         if tensor.data_ptr() != self.accum.data_ptr():
-            self.accum.copy_(tensor)
-        torch.cuda.synchronize(self.device)
+            self.accum.copy_(tensor)       # on torch's stream; resolve() waits for it
 
     def resolve(self):
+        # the merge ran on torch's stream, the context resolves on its own: order the two on the device
+        self.b.wait_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.b.resolve()
         self.b.sync()

@@ -108,12 +108,20 @@ class SceneData:
         return d, tex
 
     def save(self, path):
+        """Everything `as_desc` hands over, textures with their sampler flags and the env cube included."""
+        extra = {"texture_%d" % i: t for i, t in enumerate(self.textures)}
+        if self.env is not None:
+            extra["env"] = self.env
         np.savez_compressed(path, vertices=self.vertices, indices=self.indices, submeshes=self.submeshes,
                             index_counts=self.index_counts, xforms=self.xforms, materials=self.materials,
-                            names=np.array(self.names))
+                            names=np.array(self.names), texture_flags=np.array(self.texture_flags, np.uint32), **extra)
 
     @classmethod
     def load(cls, path):
         z = np.load(path, allow_pickle=False)
-        return cls(z["vertices"], z["indices"], z["submeshes"], z["index_counts"], z["xforms"], z["materials"],
-                   names=[str(s) for s in z["names"]])
+        flags = [int(f) for f in z["texture_flags"]] if "texture_flags" in z.files else []
+        sc = cls(z["vertices"], z["indices"], z["submeshes"], z["index_counts"], z["xforms"], z["materials"],
+                 textures=[z["texture_%d" % i] for i in range(len(flags))],
+                 env=z["env"] if "env" in z.files else None, names=[str(s) for s in z["names"]])
+        sc.texture_flags = flags
+        return sc
