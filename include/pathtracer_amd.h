@@ -213,6 +213,16 @@ void* pt_device_accum(pt_ctx* ctx);
  * hits = n*5 words: t,u,v (float bits), submesh, prim; miss = (tmax,0,0,~0,~0).
  * counters (may be NULL) = 2 uint64: hierarchy nodes visited, triangles tested. */
 int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
+/* pt_debug_intersect for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same rays and same hit records
+ * (n*8 floats in, n*5 words out), but both in DEVICE memory supplied by the caller, and the call allocates
+ * nothing: the traversal's fetch cursor and stack spill area live in a fixed 32 MiB array inside the library
+ * (one per GPU, held until the process ends).  Limits, refused with PT_ERR_TOO_LARGE: n <= 2^24 rays; a hierarchy
+ * of at most 18 levels of 8-wide nodes (pt_accel_stats.max_depth; the 3 M-triangle test scene has 11).
+ * Asynchronous on the context's main stream: read device_hits after pt_sync or behind pt_stream.  Frames queued
+ * by pt_trace must have been flushed (pt_sync) before the call.  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two contexts, or streams of the caller's own) race. */
+int pt_intersect_noalloc(pt_ctx* ctx, const float* device_rays, uint32_t n, uint32_t* device_hits);
 /* the deterministic functions used by the kernels: fn 0 sin, 1 cos, 2 log, 3 exp, 4 pow(x,y), 5 atan2(x,y),
  * 6 acos, 7 tan, 8 binary32 -> binary16 -> binary32 rounding */
 int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n);

@@ -19,7 +19,7 @@ EXPORTS = [
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
     "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
     "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_wait_stream", "pt_device_image", "pt_device_accum",
-    "pt_debug_intersect", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
+    "pt_debug_intersect", "pt_intersect_noalloc", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
 ]
 
 
@@ -91,6 +91,7 @@ def load_library():
         getattr(lib, name).restype = vp
     lib.pt_wait_stream.argtypes = [vp, vp]
     lib.pt_debug_intersect.argtypes = [vp, fp, C.c_uint32, up, C.POINTER(C.c_uint64)]
+    lib.pt_intersect_noalloc.argtypes = [vp, vp, C.c_uint32, vp]
     lib.pt_debug_math.argtypes = [vp, C.c_int, fp, fp, fp, C.c_uint32]
     lib.pt_debug_disney_sample.argtypes = [vp, C.c_uint32, fp, fp, fp, up, fp, fp, fp]
     lib.pt_debug_disney_eval.argtypes = [vp, C.c_uint32, fp, fp, fp, fp, fp, fp]
@@ -269,6 +270,10 @@ class Backend:
         counters = (C.c_uint64 * 2)()
         self._check(self.lib.pt_debug_intersect(self.h, _fp(r), len(r), _up(hits), counters))
         return hits, (counters[0], counters[1])
+
+    def intersect_noalloc(self, device_rays_ptr, n, device_hits_ptr):
+        """Closest hits of n rays in device memory into device memory, without any allocation (asynchronous: sync() before reading)."""
+        self._check(self.lib.pt_intersect_noalloc(self.h, C.c_void_p(device_rays_ptr), n, C.c_void_p(device_hits_ptr)))
 
     def debug_math(self, fn, x, y=None):
         x = np.ascontiguousarray(x, np.float32).reshape(-1)

@@ -214,6 +214,7 @@ int pt_create(int device_ordinal, pt_ctx** out)
     if (es != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) { pt_destroy(ctx); return set_error(nullptr, PT_ERR_HIP, "context allocation failed"); }
     (void)hipMemset(ctx->d_total_rays, 0, 8);
     (void)hipMemset(ctx->d_stats, 0, 128);
+    if (noalloc_init(ctx) != PT_OK) { std::string msg = ctx->error; pt_destroy(ctx); return set_error(nullptr, PT_ERR_HIP, msg); }
     *out = ctx;
     return PT_OK;
 }
@@ -658,6 +659,15 @@ int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hit
     if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_debug_intersect: hierarchy missing");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     return debug_intersect(ctx, rays, n, hits, counters);
+}
+
+int pt_intersect_noalloc(pt_ctx* ctx, const float* device_rays, uint32_t n, uint32_t* device_hits)
+{
+    if (!ctx || (n && (!device_rays || !device_hits))) return PT_ERR_INVALID;
+    if (((uintptr_t)device_rays & 15u) || ((uintptr_t)device_hits & 3u)) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: rays must be 16-byte aligned, hits 4-byte aligned");
+    if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: hierarchy missing");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return intersect_noalloc(ctx, device_rays, n, device_hits);
 }
 
 int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n)

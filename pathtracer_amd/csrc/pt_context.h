@@ -93,6 +93,7 @@ struct pt_ctx {
     size_t wave_trace_len = 0;
     uint32_t wave_trace_rounds = 0, wave_trace_waves = 0;
     unsigned long long* d_total_rays = nullptr;
+    void* noalloc_scratch = nullptr;         // address, on this context's GPU, of the fixed scratch array of pt_intersect_noalloc
     unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested, [2] fetch cursor of pt_debug_intersect
 
     pt_params params{};
@@ -124,6 +125,8 @@ int sync_streams(pt_ctx* ctx);     // host waits for every chain
 int collect_slot(pt_ctx* ctx, pt_prof_slot& slot);   // waits for that frame, adds it to the timing window
 int join_chains(pt_ctx* ctx);      // main stream waits for the other chains (no host wait)
 int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
+int noalloc_init(pt_ctx* ctx);
+int intersect_noalloc(pt_ctx* ctx, const float* d_rays, uint32_t n, uint32_t* d_hits);
 int debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n);
 int debug_disney(pt_ctx* ctx, bool sample, uint32_t n, const float* surf, const float* V, const float* N,
                  const float* Lin, uint32_t* seeds, float* f, float* Lout, float* pdf);
@@ -133,6 +136,8 @@ SceneView scene_view(const pt_ctx* ctx);
 // words of one chain's counter block: rounds + 1 rows of queue sizes, as many of fetch cursors, one row whose first
 // word counts the deferred rays
 inline size_t pt_chain_words(uint32_t rounds, uint32_t shards_per_chain) { return ((size_t)2 * (rounds + 1) + 1) * shards_per_chain; }
+
+#define PT_NOALLOC_MAX_RAYS (1u << 24)
 
 #define PT_SYNC(ctx)                                                                              \
     do {                                                                                          \

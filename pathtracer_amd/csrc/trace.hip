@@ -917,6 +917,51 @@ int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, 
     return PT_OK;
 }
 
+// ---- closest hits without any allocation ------------------------------------------------------------
+// Scratch of the allocation-free ray query: a 256-byte header (two statistics counters and the fetch cursor of
+// the persistent waves, which must start at zero) followed by the traversal-stack spill area of
+// PT_NOALLOC_WAVES waves, PT_NOALLOC_STACK entries of 64 lanes each.  One copy per GPU, held until the process
+// ends; every call on a GPU uses it, so calls that overlap on one GPU race.
+static constexpr uint32_t PT_NOALLOC_WAVES = 512;
+static constexpr uint32_t PT_NOALLOC_STACK = 128;    // stack entries per lane: hierarchies of up to 18 levels (7 per level + 1)
+static constexpr size_t PT_NOALLOC_HEADER = 256;
+static constexpr size_t PT_NOALLOC_BYTES = PT_NOALLOC_HEADER + (size_t)PT_NOALLOC_WAVES * PT_NOALLOC_STACK * 64 * sizeof(uint2);
+static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_BYTES];
+
+// the array's address on the device that is current; called once per context, at pt_create
+int noalloc_init(pt_ctx* ctx)
+{
+    void* ptr = nullptr;
+    PT_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return set_error(ctx, PT_ERR_HIP, "hipGetSymbolAddress returned a null address for the ray-query scratch");
+    ctx->noalloc_scratch = ptr;
+    return PT_OK;
+}
+
+int intersect_noalloc(pt_ctx* ctx, const float* d_rays, uint32_t n, uint32_t* d_hits)
+{
+    if (ctx->stack_entries > PT_NOALLOC_STACK)
+        return set_error(ctx, PT_ERR_TOO_LARGE, "pt_intersect_noalloc: the hierarchy has " + std::to_string(ctx->accel_stats.max_depth) +
+                         " levels; the fixed scratch holds traversal stacks for at most 18");
+    if (n > PT_NOALLOC_MAX_RAYS) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_intersect_noalloc: more than 2^24 rays in one call");
+    if (!ctx->pending.empty()) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: frames are queued; call pt_sync first");
+    if (!ctx->noalloc_scratch) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: scratch address missing");
+    int rc = join_chains(ctx);          // event record + stream wait only
+    if (rc) return rc;
+    if (n == 0) return PT_OK;
+    hipStream_t st = ctx->stream;
+    unsigned char* base = static_cast<unsigned char*>(ctx->noalloc_scratch);
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(base);
+    PT_HIP(ctx, hipMemsetAsync(base, 0, PT_NOALLOC_HEADER, st));     // the cursor and the counters start at zero; the spill area needs no clearing
+    uint32_t blocks = (n + EXT_BLOCK - 1) / EXT_BLOCK;
+    if (blocks > PT_NOALLOC_WAVES) blocks = PT_NOALLOC_WAVES;
+    k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(stats + 2), reinterpret_cast<const float4*>(d_rays), d_hits,
+                                                    reinterpret_cast<uint2*>(base + PT_NOALLOC_HEADER), ctx->stack_entries, stats);
+    PT_HIP(ctx, hipGetLastError());
+    ctx->main_dirty = true;
+    return PT_OK;
+}
+
 int debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n)
 {
     hipStream_t st = ctx->stream;
