@@ -544,4 +544,32 @@ void orc_disney_eval(const float* surf, const float* V, const float* N, const fl
     f[0] = r.x; f[1] = r.y; f[2] = r.z;
 }
 
+// ClosestHit.glsl:144-226 for one given hit: out = 26 floats
+// Distance, Albedo3, Roughness, Metallic, Emission3, WorldNormal3, Anisotropic, Subsurface, SpecularTint, Sheen,
+// SheenTint, Clearcoat, ClearcoatRoughness, SpecTrans, ior, ax, ay, eta.  Returns -1 if the scene has no such triangle.
+int orc_closest_hit(orc_ctx* h, uint32_t submesh, uint32_t prim, float u, float v, float t, const float* dir, float* out)
+{
+    const Ctx& c = h->c;
+    for (size_t k = 0; k < c.tris.size(); k++) {
+        if (c.tris[k].submesh != submesh || c.tris[k].prim != prim) continue;
+        Hit hit;
+        hit.t = t; hit.u = u; hit.v = v; hit.tri = (uint32_t)k;
+        Payload p = closest_hit(c, hit, V3(dir[0], dir[1], dir[2]));
+        const float vals[26] = {p.Distance, p.Albedo.x, p.Albedo.y, p.Albedo.z, p.Roughness, p.Metallic, p.Emission.x, p.Emission.y, p.Emission.z,
+                                p.WorldNormal.x, p.WorldNormal.y, p.WorldNormal.z, p.Anisotropic, p.Subsurface, p.SpecularTint, p.Sheen, p.SheenTint,
+                                p.Clearcoat, p.ClearcoatRoughness, p.SpecTrans, p.ior, p.ax, p.ay, p.eta};
+        std::memcpy(out, vals, sizeof(vals));
+        return 0;
+    }
+    return -1;
+}
+
+// TracePath (RayGen.glsl:106-176) of one given camera ray with the context's parameters; *seed advances as in the shader
+void orc_trace_path(orc_ctx* h, const float* origin, const float* dir, uint32_t* seed, int use_bvh, float* radiance)
+{
+    ThreadStats st;
+    vec3 r = trace_path(h->c, V3(origin[0], origin[1], origin[2]), V3(dir[0], dir[1], dir[2]), *seed, use_bvh != 0, st, nullptr);
+    radiance[0] = r.x; radiance[1] = r.y; radiance[2] = r.z;
+}
+
 } // extern "C"

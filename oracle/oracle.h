@@ -80,6 +80,11 @@ void orc_preetham_sky(float turbidity, float azimuth, float inclination, uint32_
  * V, N world vectors; returns f (3), L (3), pdf and the advanced seed. */
 void orc_disney_sample(const float* surf, const float* V, const float* N, uint32_t* seed, float* f, float* L, float* pdf);
 void orc_disney_eval(const float* surf, const float* V, const float* N, const float* L, float* f, float* pdf);
+/* ClosestHit.glsl:144-226 for the hit (submesh, prim, u, v, t) of a ray with direction dir: 26 payload floats
+ * (Distance, Albedo3, Roughness, Metallic, Emission3, WorldNormal3, the nine Disney extras, ax, ay, eta) */
+int orc_closest_hit(orc_ctx*, uint32_t submesh, uint32_t prim, float u, float v, float t, const float* dir, float* out26);
+/* TracePath (RayGen.glsl:106-176) of one ray under the context's parameters; the seed advances as in the shader */
+void orc_trace_path(orc_ctx*, const float* origin, const float* dir, uint32_t* seed, int use_bvh, float* radiance);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,9 @@ def lib():
     L.orc_disney_sample.restype = None
     L.orc_disney_eval.argtypes = [fp, fp, fp, fp, fp, fp]
     L.orc_disney_eval.restype = None
+    L.orc_closest_hit.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, fp, fp]
+    L.orc_trace_path.argtypes = [vp, fp, fp, up, C.c_int, fp]
+    L.orc_trace_path.restype = None
     _lib = L
     return L
 
@@ -164,6 +167,29 @@ class Oracle:
         hits = np.empty((len(r), 5), np.uint32)
         self.L.orc_intersect(self.h, _fp(r), len(r), _up(hits), 1 if use_bvh else 0, self.threads)
         return hits
+
+
+PAYLOAD_FIELDS = ["Distance", "Albedo.x", "Albedo.y", "Albedo.z", "Roughness", "Metallic", "Emission.x", "Emission.y", "Emission.z",
+                  "WorldNormal.x", "WorldNormal.y", "WorldNormal.z", "Anisotropic", "Subsurface", "SpecularTint", "Sheen", "SheenTint",
+                  "Clearcoat", "ClearcoatRoughness", "SpecTrans", "ior", "ax", "ay", "eta"]
+
+
+def closest_hit(oracle, submesh, prim, u, v, t, direction):
+    """Payload of ClosestHit.glsl for one hit, as a dict of the fields downstream code reads."""
+    d = np.ascontiguousarray(direction, np.float32)
+    out = np.zeros(26, np.float32)
+    assert oracle.L.orc_closest_hit(oracle.h, submesh, prim, u, v, t, _fp(d), _fp(out)) == 0
+    return dict(zip(PAYLOAD_FIELDS, out[:24].tolist()))
+
+
+def trace_path(oracle, origin, direction, seed, use_bvh=False):
+    """TracePath of one ray: (radiance (3,), advanced seed)."""
+    o = np.ascontiguousarray(origin, np.float32)
+    d = np.ascontiguousarray(direction, np.float32)
+    s = C.c_uint32(int(seed))
+    rad = np.zeros(3, np.float32)
+    oracle.L.orc_trace_path(oracle.h, _fp(o), _fp(d), C.byref(s), 1 if use_bvh else 0, _fp(rad))
+    return rad, s.value
 
 
 def pcg_hash(seed):
