@@ -58,3 +58,9 @@ def cornell_camera(width, height):
     """Fixed view into the open front (+z side) of CornellBox.gltf scaled by 0.1 (RayTracingLayer.cpp:32-34)."""
     view = look_at((-0.025, 0.26, 0.75), (-0.025, 0.26, -0.3))
     return camera_buffer(view, perspective(45.0, width / height, 0.01, 100.0))
+
+
+def suzanne_camera(width, height):
+    """Three-quarter view of Suzanne.gltf (the head spans x in [-1.34, 1.34], y in [-0.97, 0.95], z in [-0.80, 0.83])."""
+    view = look_at((0.9, 0.4, 2.5), (0.0, -0.02, 0.0))
+    return camera_buffer(view, perspective(45.0, width / height, 0.01, 100.0))

@@ -8,6 +8,10 @@ reference checkout is mounted at /root/reference; the GPU box only reads the res
                       for the sizes the tests use, so goldens do not depend on the host's LAPACK rounding.
   pcg_kat.json        first 16 outputs of PCG_Hash (Globals.h:54-59) for four seeds, computed with Python
                       integers (independent of the oracle).
+  suzanne_scene.npz   scene tables of PathTracer/assets/models/Suzanne/glTF/Suzanne.gltf (3 936 triangles with tangents
+                      and uv) and its two PNG textures decoded with Pillow (RGBA8, 1024 x 1024 each; base colour and
+                      metallic-roughness), by the independent Python reader.  Data only.
+  suzanne_cameras.npz CameraBuffer matrices of pathtracer_amd.camera.suzanne_camera for the sizes the tests use.
   cornell_primary_ids_64.npy      (submesh, primitive) of the primary hit per pixel, 64x64, from the
                       oracle's BRUTE-FORCE intersector (no hierarchy involved).
   cornell_radiance_128_16spp.npy  accumulation image after frames 1..17 (16 accumulated samples),
@@ -34,7 +38,22 @@ def cornell():
     print("cornell_scene.npz:", sc.num_triangles, "triangles")
 
 
+def suzanne():
+    from PIL import Image
+    base = os.path.join(REF, "Suzanne", "glTF")
+    sc = gltf_py.load_gltf(os.path.join(base, "Suzanne.gltf"), use_textures=True)
+    import json
+    g = json.load(open(os.path.join(base, "Suzanne.gltf")))
+    sc.textures = [np.ascontiguousarray(np.asarray(Image.open(os.path.join(base, im["uri"])).convert("RGBA"), np.uint8)) for im in g["images"]]
+    sc.texture_flags = [0] * len(sc.textures)          # the asset's one sampler object is empty: bilinear, repeat
+    sc.save(os.path.join(HERE, "suzanne_scene.npz"))
+    print("suzanne_scene.npz:", sc.num_triangles, "triangles,", [t.shape for t in sc.textures])
+
+
 def cameras():
+    from pathtracer_amd import camera as cam_
+    np.savez(os.path.join(HERE, "suzanne_cameras.npz"),
+             **{"%dx%d" % wh: cam_.suzanne_camera(*wh) for wh in [(1920, 1080), (240, 135), (96, 54)]})
     from pathtracer_amd import camera
     np.savez(os.path.join(HERE, "cornell_cameras.npz"),
              **{"%dx%d" % wh: camera.cornell_camera(*wh) for wh in [(64, 64), (128, 128), (512, 512), (1920, 1080), (96, 64), (24, 16), (16, 16)]})
@@ -76,6 +95,7 @@ def oracle_goldens():
 if __name__ == "__main__":
     if os.path.exists(REF):
         cornell()
+        suzanne()
     cameras()
     pcg()
     oracle_goldens()

@@ -334,6 +334,34 @@ def test_bvh_equals_brute_force_on_cornell(cornell):
     assert np.array_equal(o.intersect(rays, use_bvh=True), o.intersect(rays, use_bvh=False))
 
 
+def test_suzanne_fixture_bvh_equals_brute_force_and_keeps_its_textures(tmp_path):
+    """The textured reference asset (Suzanne.gltf + its two PNGs as committed data): hierarchy = brute force for random
+    rays and for a whole small frame; the scene file round-trips with textures and sampler flags."""
+    sc = SceneData.load(os.path.join(GOLDEN, "suzanne_scene.npz"))
+    assert sc.num_triangles == 3936 and [t.shape for t in sc.textures] == [(1024, 1024, 4)] * 2 and sc.texture_flags == [0, 0]
+    assert sc.materials.view(np.int32)[0, 10:13].tolist() == [0, 1, -1]
+    o = oracle_lib.Oracle(sc)
+    rays = random_rays(np.random.default_rng(9), 4000, [-1.5, -1.1, -1.0], [1.5, 1.1, 1.0])
+    hb = o.intersect(rays, use_bvh=True)
+    assert np.array_equal(hb, o.intersect(rays, use_bvh=False)) and (hb[:, 3] != M32).sum() > 500
+    cam = np.load(os.path.join(GOLDEN, "suzanne_cameras.npz"))["96x54"]
+    o.resize(96, 54)
+    o.set_camera(cam)
+    o.set_params(Params.reference(spp_per_frame=1, max_bounces=6))
+    for f in (1, 2):
+        o.trace(f, use_bvh=True)
+    a, ids = o.read_accum(), o.read_primary_ids()
+    for f in (1, 2):
+        o.trace(f, use_bvh=False)
+    assert np.array_equal(a.view(np.uint32), o.read_accum().view(np.uint32)) and np.array_equal(ids, o.read_primary_ids())
+    assert (ids[..., 0] != M32).mean() > 0.2
+    path = str(tmp_path / "s.npz")
+    sc.texture_flags = [5, 16]
+    sc.save(path)
+    back = SceneData.load(path)
+    assert back.texture_flags == [5, 16] and all(np.array_equal(x, y) for x, y in zip(back.textures, sc.textures))
+
+
 def test_hit_respects_tmin_tmax_and_tie_rule():
     # two coincident quads (4 triangles in 2 submeshes) at z = -1: equal t -> lowest (submesh, prim) wins
     v = np.zeros((8, 12), np.float32)
