@@ -210,12 +210,12 @@ void* pt_device_accum(pt_ctx* ctx);
 
 /* ---- inspection hooks used by the parity tests ------------------------------------- */
 /* closest hit of caller-supplied rays: rays = n*8 floats (o.xyz, tmin, d.xyz, tmax);
- * hits = n*5 words: t,u,v (float bits), submesh, prim; miss = (tmax,0,0,~0,~0).
+ * hits = n*5 words: t,u,v (float bits), submesh, prim; miss = (tmax,0,0,~0,~0).  tmin must be >= 0.
  * counters (may be NULL) = 2 uint64: hierarchy nodes visited, triangles tested. */
 int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
 /* pt_debug_intersect for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same rays and same hit records
- * (n*8 floats in, n*5 words out), but both in DEVICE memory supplied by the caller, and the call allocates
+ * (n*8 floats in, n*5 words out; a negative or NaN tmin is taken as 0), but both in DEVICE memory supplied by the caller, and the call allocates
  * nothing: the traversal's fetch cursor and stack spill area live in a fixed 32 MiB array inside the library
  * (one per GPU, held until the process ends).  Limits, refused with PT_ERR_TOO_LARGE: n <= 2^24 rays; a hierarchy
  * of at most 18 levels of 8-wide nodes (pt_accel_stats.max_depth; the 3 M-triangle test scene has 11).

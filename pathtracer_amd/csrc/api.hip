@@ -266,8 +266,11 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* s)
 {
     if (!ctx || !s) return PT_ERR_INVALID;
     PT_HIP(ctx, hipSetDevice(ctx->device));
-    if (!s->vertices || !s->indices || !s->submeshes || !s->submesh_index_counts || !s->submesh_xforms || !s->materials)
-        if (s->num_submeshes) return set_error(ctx, PT_ERR_INVALID, "pt_scene_upload: a required table is NULL");
+    // every table is checked against its own count
+    if ((s->num_vertices && !s->vertices) || (s->num_indices && !s->indices) || (s->num_materials && !s->materials) ||
+        (s->num_textures && !s->textures) || (s->num_submeshes && (!s->submeshes || !s->submesh_index_counts || !s->submesh_xforms)))
+        return set_error(ctx, PT_ERR_INVALID, "pt_scene_upload: a table with a non-zero count is NULL");
+    if (s->env_rgba && s->env_face_size > 8192) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_scene_upload: env_face_size must not exceed 8192");
     // validate every index the kernels will follow, so that no launch can read out of bounds
     std::vector<uint32_t> tri_off(s->num_submeshes + 1, 0);
     for (uint32_t i = 0; i < s->num_submeshes; i++) {
@@ -442,6 +445,8 @@ int pt_set_params(pt_ctx* ctx, const pt_params* p)
 {
     if (!ctx || !p) return PT_ERR_INVALID;
     if (p->spp_per_frame == 0 || p->max_bounces == 0) return set_error(ctx, PT_ERR_INVALID, "spp_per_frame and max_bounces must be >= 1");
+    // the traversal orders subtrees by the bit pattern of their entry distance, which is monotonic for non-negative floats only
+    if (!(p->tmin >= 0.0f) || !(p->tmax == p->tmax)) return set_error(ctx, PT_ERR_INVALID, "tmin must be >= 0 and tmax must not be NaN");
     if (p->spp_per_frame > 0xFFFFu || p->max_bounces > 0xFFFFu || (uint64_t)p->spp_per_frame * p->max_bounces > 65536ull)
         return set_error(ctx, PT_ERR_TOO_LARGE, "spp_per_frame * max_bounces must not exceed 65536");
     if (!ctx->pending.empty()) {      // frames already handed in keep the parameters they were traced with
@@ -657,6 +662,8 @@ int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hit
 {
     if (!ctx || (n && (!rays || !hits))) return PT_ERR_INVALID;
     if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_debug_intersect: hierarchy missing");
+    for (uint32_t i = 0; i < n; i++)
+        if (!(rays[(size_t)i * 8 + 3] >= 0.0f)) return set_error(ctx, PT_ERR_INVALID, "pt_debug_intersect: ray " + std::to_string(i) + " has tmin < 0 or NaN");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     return debug_intersect(ctx, rays, n, hits, counters);
 }

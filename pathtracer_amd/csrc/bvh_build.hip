@@ -813,7 +813,7 @@ int refit_accel(pt_ctx* ctx)
     float lo[3], hi[3], pad;
     {
         int rc = scene_extent(ctx, bounds.p, lo, hi, pad);
-        if (rc) return rc;
+        if (rc) { ctx->accel_built = false; return rc; }     // the triangles are already rewritten: the old hierarchy no longer fits them
     }
     for (size_t d = ctx->level_start.size() - 1; d-- > 0;) {
         uint32_t first = ctx->level_start[d], count = ctx->level_start[d + 1] - first;

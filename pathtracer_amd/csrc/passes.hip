@@ -176,9 +176,11 @@ __global__ void k_preetham(float turbidity, float azimuth, float inclination, ui
 static int replace_env(pt_ctx* ctx, uint32_t n)
 {
     PT_SYNC(ctx);
+    // the new cube is allocated before the old one goes, so that a failed allocation leaves the scene as it was
+    float* fresh = nullptr;
+    PT_HIP(ctx, hipMalloc((void**)&fresh, (size_t)6 * n * n * 16));
     if (ctx->d_env) (void)hipFree(ctx->d_env);
-    ctx->d_env = nullptr;
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_env, (size_t)6 * n * n * 16));
+    ctx->d_env = fresh;
     ctx->env_n = n;
     return PT_OK;
 }

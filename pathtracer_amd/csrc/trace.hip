@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
             float4 ro = rays[2 * i], rd = rays[2 * i + 1];
             o = V3(ro.x, ro.y, ro.z);
             d = V3(rd.x, rd.y, rd.z);
-            tn = ro.w;
+            tn = fmaxf(ro.w, 0.0f);        // tmin >= 0 is part of the contract (the host checks host-side rays); NaN -> 0
             tx = rd.w;
             return 0u;
         },

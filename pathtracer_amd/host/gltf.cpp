@@ -152,6 +152,19 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
     size_t slash = path.find_last_of("/\\");
     if (slash != std::string::npos) dir = path.substr(0, slash + 1);
 
+    // a non-negative integer field (offsets, counts, strides, indices into the file's arrays): anything negative,
+    // fractional, non-finite or beyond 2^53 is refused before it can turn into a huge size_t
+    auto field = [](const Json& o, const char* key, double dflt) -> size_t {
+        double v = o.get(key, dflt);
+        if (!(v >= 0.0) || v > 9007199254740992.0 || v != std::floor(v))
+            throw std::runtime_error(std::string("gltf: '") + key + "' is not a non-negative integer");
+        return (size_t)v;
+    };
+    auto index_of = [](double v, size_t n, const char* what) -> size_t {
+        if (!(v >= 0.0) || v != std::floor(v) || v >= (double)n) throw std::runtime_error(std::string("gltf: ") + what + " index out of range");
+        return (size_t)v;
+    };
+
     std::vector<std::string> buffers;
     if (const Json* bj = g.find("buffers"))
         for (const Json& b : bj->arr) {
@@ -163,26 +176,35 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
             } else {
                 buffers.push_back(read_file(dir + uri, true));
             }
-            if (buffers.back().size() < (size_t)b.geti("byteLength", 0))
+            if (buffers.back().size() < field(b, "byteLength", 0))
                 throw std::runtime_error("gltf: buffer '" + uri.substr(0, 40) + "' is shorter than its byteLength");
         }
 
-    auto accessor = [&](int64_t idx) {
-        const Json& a = g.at("accessors").at((size_t)idx);
+    auto accessor = [&](double idx) {
+        const Json& accs = g.at("accessors");
+        const Json& a = accs.at(index_of(idx, accs.size(), "accessor"));
         if (a.find("sparse")) throw std::runtime_error("gltf: sparse accessors are not supported");
-        const Json& bv = g.at("bufferViews").at((size_t)a.geti("bufferView", -1));
+        const Json& bvs = g.at("bufferViews");
+        const Json& bv = bvs.at(index_of(a.get("bufferView", -1.0), bvs.size(), "bufferView"));
         Accessor r;
         r.componentType = (int)a.geti("componentType", 0);
         r.ncomp = num_comp(a.gets("type", ""));
-        r.count = (size_t)a.geti("count", 0);
+        r.count = field(a, "count", 0);
         const Json* nj = a.find("normalized");
         r.normalized = nj && nj->is(Json::Bool) && nj->b;
-        size_t elem = comp_size(r.componentType) * (size_t)r.ncomp;
-        r.stride = (size_t)bv.geti("byteStride", 0);
+        const size_t elem = comp_size(r.componentType) * (size_t)r.ncomp;
+        r.stride = field(bv, "byteStride", 0);
         if (r.stride == 0) r.stride = elem;
-        size_t off = (size_t)bv.geti("byteOffset", 0) + (size_t)a.geti("byteOffset", 0);
-        const std::string& buf = buffers.at((size_t)bv.geti("buffer", 0));
-        if (r.count && off + (r.count - 1) * r.stride + elem > buf.size()) throw std::runtime_error("gltf: accessor exceeds its buffer");
+        if (r.stride < elem) throw std::runtime_error("gltf: byteStride is smaller than the element");
+        const size_t off_bv = field(bv, "byteOffset", 0), off_a = field(a, "byteOffset", 0);
+        const std::string& buf = buffers.at(index_of(bv.get("buffer", 0.0), buffers.size(), "buffer"));
+        const size_t size = buf.size();
+        // overflow-safe: every term is checked against what is left of the buffer
+        if (off_bv > size || off_a > size - off_bv) throw std::runtime_error("gltf: accessor exceeds its buffer");
+        const size_t off = off_bv + off_a;
+        if (r.count) {
+            if (elem > size - off || r.count - 1 > (size - off - elem) / r.stride) throw std::runtime_error("gltf: accessor exceeds its buffer");
+        }
         r.base = reinterpret_cast<const uint8_t*>(buf.data()) + off;
         return r;
     };
@@ -264,12 +286,22 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
         const Json& g;
         decltype(accessor)& acc;
         int32_t& default_material;
-        void walk(size_t ni, const Mat4d& parent)
+        std::vector<char> on_path;      // nodes between the root and the current one: a node that names an ancestor is a cycle
+        void walk(double nd, const Mat4d& parent, int depth)
         {
-            const Json& node = g.at("nodes").at(ni);
+            const Json& nodes = g.at("nodes");
+            if (!(nd >= 0.0) || nd != std::floor(nd) || nd >= (double)nodes.size()) throw std::runtime_error("gltf: node index out of range");
+            const size_t ni = (size_t)nd;
+            if (on_path.size() < nodes.size()) on_path.resize(nodes.size(), 0);
+            if (on_path[ni]) throw std::runtime_error("gltf: the node hierarchy has a cycle");
+            if (depth > 256) throw std::runtime_error("gltf: the node hierarchy is deeper than 256 levels");
+            on_path[ni] = 1;
+            const Json& node = nodes.at(ni);
             Mat4d world = parent * node_local(node);
             if (const Json* mi = node.find("mesh")) {
-                const Json& mesh = g.at("meshes").at((size_t)mi->num);
+                const Json& meshes = g.at("meshes");
+                if (!(mi->num >= 0.0) || mi->num != std::floor(mi->num) || mi->num >= (double)meshes.size()) throw std::runtime_error("gltf: mesh index out of range");
+                const Json& mesh = meshes.at((size_t)mi->num);
                 const Json& prims = mesh.at("primitives");
                 for (size_t pi = 0; pi < prims.size(); pi++) {
                     const Json& prim = prims.at(pi);
@@ -279,9 +311,14 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
                     if (pos.ncomp != 3) throw std::runtime_error("gltf: POSITION must be VEC3");
                     size_t n = pos.count;
                     Accessor uv{}, nrm{}, tan{};
-                    if (const Json* j = at.find("TEXCOORD_0")) uv = acc((int64_t)j->num);
-                    if (const Json* j = at.find("NORMAL")) nrm = acc((int64_t)j->num);
-                    if (const Json* j = at.find("TANGENT")) tan = acc((int64_t)j->num);
+                    if (const Json* j = at.find("TEXCOORD_0")) uv = acc(j->num);
+                    if (const Json* j = at.find("NORMAL")) nrm = acc(j->num);
+                    if (const Json* j = at.find("TANGENT")) tan = acc(j->num);
+                    // the loops below read 2, 3 and 4 components: an accessor of a narrower type would be read past its extent
+                    if (uv.base && uv.ncomp < 2) throw std::runtime_error("gltf: TEXCOORD_0 must have at least 2 components");
+                    if (nrm.base && nrm.ncomp < 3) throw std::runtime_error("gltf: NORMAL must be VEC3");
+                    if (tan.base && tan.ncomp < 4) throw std::runtime_error("gltf: TANGENT must be VEC4");
+                    if (n > 0x7FFFFFFFu || self.m_Vertices.size() + n > 0x7FFFFFFFu) throw std::runtime_error("gltf: more than 2^31 vertices");
                     SubMesh sm;
                     sm.VertexOffset = (uint32_t)self.m_Vertices.size();
                     sm.IndexOffset = (uint32_t)self.m_Indices.size();
@@ -297,7 +334,9 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
                     }
                     size_t ni_count;
                     if (const Json* ij = prim.find("indices")) {
-                        Accessor ia = acc((int64_t)ij->num);
+                        Accessor ia = acc(ij->num);
+                        if (ia.ncomp != 1) throw std::runtime_error("gltf: indices must be SCALAR");
+                        if (ia.count > 0xFFFFFFFFu - self.m_Indices.size()) throw std::runtime_error("gltf: more than 2^32 indices");
                         ni_count = ia.count;
                         for (size_t i = 0; i < ia.count; i++) {
                             double v = read_comp(ia, i, 0);
@@ -333,13 +372,14 @@ MeshSource::MeshSource(const std::string& path) : m_Path(path)
                 }
             }
             if (const Json* ch = node.find("children"))
-                for (const Json& c : ch->arr) walk((size_t)c.num, world);
+                for (const Json& c : ch->arr) walk(c.num, world, depth + 1);
+            on_path[ni] = 0;
         }
-    } walker{*this, g, accessor, default_material};
+    } walker{*this, g, accessor, default_material, {}};
 
-    size_t scene = (size_t)g.geti("scene", 0);
-    const Json& roots = g.at("scenes").at(scene).at("nodes");
-    for (const Json& r : roots.arr) walker.walk((size_t)r.num, Mat4d::identity());
+    const Json& scenes = g.at("scenes");
+    const Json& roots = scenes.at(index_of(g.get("scene", 0.0), scenes.size(), "scene")).at("nodes");
+    for (const Json& r : roots.arr) walker.walk(r.num, Mat4d::identity(), 0);
     if (m_SubMeshes.empty()) throw std::runtime_error("gltf: no triangle primitives in " + path);
 }
 

@@ -46,7 +46,13 @@ struct Json {
         const Json* j = find(key);
         return j && j->type == Number ? j->num : dflt;
     }
-    int64_t geti(const std::string& key, int64_t dflt) const { return (int64_t)get(key, (double)dflt); }
+    int64_t geti(const std::string& key, int64_t dflt) const
+    {
+        double v = get(key, (double)dflt);
+        if (!(v == v)) return dflt;                                   // NaN
+        const double lim = 4611686018427387904.0;                    // 2^62: the cast below is defined for every value left
+        return (int64_t)(v > lim ? lim : (v < -lim ? -lim : v));
+    }
     std::string gets(const std::string& key, const std::string& dflt) const
     {
         const Json* j = find(key);

@@ -593,6 +593,26 @@ def test_error_reporting(backend, cornell):
         backend.set_params(Params.reference(spp_per_frame=0))
     with pytest.raises(BackendError):
         backend.resize(0, 4)
+    # entry distances are ordered by their bit patterns: a negative (or NaN) tmin is refused, not mis-sorted
+    for tmin in (-1e-3, float("nan")):
+        with pytest.raises(BackendError) as e:
+            backend.set_params(Params.reference(tmin=tmin))
+        assert "tmin" in str(e.value)
+        rays = random_rays(np.random.default_rng(0), 4, -0.2, 0.2, tmin=tmin)
+        with pytest.raises(BackendError):
+            backend.debug_intersect(rays)
+    # a table with a non-zero count must not be NULL
+    import ctypes as C
+    desc, keep = cornell.as_desc()
+    desc.num_submeshes = 0
+    desc.vertices = C.POINTER(C.c_float)()
+    assert backend.lib.pt_scene_upload(backend.h, C.byref(desc)) == 1
+    desc, keep = cornell.as_desc()
+    desc.num_textures = 2
+    desc.textures = C.POINTER(type(keep[0]))()
+    assert backend.lib.pt_scene_upload(backend.h, C.byref(desc)) == 1
+    backend.scene_upload(cornell)
+    backend.build_accel()
 
 
 # ---- compute passes around the path tracer ---------------------------------------------------------------------

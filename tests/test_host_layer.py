@@ -59,6 +59,71 @@ def write_gltf(tmp_path):
     return str(path)
 
 
+def hostile_gltfs(tmp_path):
+    """Structurally valid JSON whose numbers aim at the loader's arithmetic: each must be refused, not read out of bounds."""
+    import base64
+    import copy
+    import json
+    import struct
+    pos = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0)]
+    blob = (b"".join(struct.pack("<3f", *p) for p in pos) + b"".join(struct.pack("<3f", 0, 0, 1) for _ in pos) +
+            b"".join(struct.pack("<2f", p[0], p[1]) for p in pos) + b"".join(struct.pack("<4f", 1, 0, 0, 1) for _ in pos) + struct.pack("<6H", 0, 1, 2, 2, 1, 3))
+    good = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0, "children": [1]}, {"mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2, "TANGENT": 3}, "indices": 4}]}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 2, "componentType": 5126, "count": 4, "type": "VEC2"}, {"bufferView": 3, "componentType": 5126, "count": 4, "type": "VEC4"},
+                      {"bufferView": 4, "componentType": 5123, "count": 6, "type": "SCALAR"}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 48}, {"buffer": 0, "byteOffset": 48, "byteLength": 48},
+                        {"buffer": 0, "byteOffset": 96, "byteLength": 32}, {"buffer": 0, "byteOffset": 128, "byteLength": 64},
+                        {"buffer": 0, "byteOffset": 192, "byteLength": 12}],
+        "buffers": [{"uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode(), "byteLength": len(blob)}],
+    }
+
+    def variant(edit):
+        g = copy.deepcopy(good)
+        edit(g)
+        return g
+    bad = {
+        "scalar_normal": variant(lambda g: g["accessors"][1].update(type="SCALAR", bufferView=4, componentType=5123, count=6)),   # 3 components read from a 2-byte element
+        "scalar_tangent_at_end": variant(lambda g: g["accessors"][3].update(type="SCALAR", bufferView=4, componentType=5123, count=6)),
+        "vec2_position": variant(lambda g: g["accessors"][0].update(type="VEC2")),
+        "negative_view_offset": variant(lambda g: g["bufferViews"][0].update(byteOffset=-16)),
+        "negative_accessor_offset": variant(lambda g: g["accessors"][0].update(byteOffset=-8)),
+        "fractional_offset": variant(lambda g: g["accessors"][0].update(byteOffset=0.5)),
+        "huge_count": variant(lambda g: g["accessors"][0].update(count=2 ** 61)),
+        "count_times_stride_wraps": variant(lambda g: (g["accessors"][0].update(count=2 ** 60 + 1), g["bufferViews"][0].update(byteStride=16))),
+        "stride_below_element": variant(lambda g: g["bufferViews"][0].update(byteStride=4)),
+        "huge_offset": variant(lambda g: g["bufferViews"][2].update(byteOffset=1e300)),
+        "self_child": variant(lambda g: g["nodes"][1].update(children=[1])),
+        "cycle": variant(lambda g: g["nodes"][1].update(children=[0])),
+        "negative_accessor": variant(lambda g: g["meshes"][0]["primitives"][0]["attributes"].update(POSITION=-1)),
+        "negative_view": variant(lambda g: g["accessors"][0].update(bufferView=-3)),
+        "bad_buffer": variant(lambda g: g["bufferViews"][0].update(buffer=7)),
+        "vec3_indices": variant(lambda g: g["accessors"][4].update(type="VEC3", count=2)),
+        "bad_scene": variant(lambda g: g.update(scene=-1)),
+        "bad_mesh": variant(lambda g: g["nodes"][0].update(mesh=1e9)),
+    }
+    deep = copy.deepcopy(good)
+    deep["nodes"] = [{"children": [i + 1]} for i in range(400)] + [{"mesh": 0}]
+    bad["too_deep"] = deep
+    out = {}
+    for name, g in [("good", good)] + list(bad.items()):
+        path = tmp_path / ("hostile_%s.gltf" % name)
+        path.write_text(json.dumps(g))
+        out[name] = str(path)
+    return out
+
+
+def test_gltf_loader_refuses_hostile_accessors(tmp_path):
+    files = hostile_gltfs(tmp_path)
+    ok = host.MeshSource(files.pop("good")).scene_data()
+    assert ok.num_triangles == 4 and np.array_equal(ok.vertices[:4, 8:12], np.tile([1, 0, 0, 1], (4, 1)))
+    for name, path in files.items():
+        with pytest.raises(RuntimeError):
+            host.MeshSource(path)
+
+
 def assert_same_scene(a, b):
     assert np.array_equal(a.vertices, b.vertices)
     assert np.array_equal(a.indices, b.indices)
@@ -419,7 +484,7 @@ def test_parsers_survive_mutated_files(tmp_path):
         img.save(tmp_path / name, **kw)
         files.append(str(tmp_path / name))
     hdr_py.write_hdr(tmp_path / "a.hdr", hdr_py.float_to_rgbe(rng.uniform(0, 4, (16, 32, 3))))
-    files += [str(tmp_path / "a.hdr"), write_gltf(tmp_path)]
+    files += [str(tmp_path / "a.hdr"), write_gltf(tmp_path)] + sorted(hostile_gltfs(tmp_path).values())
     env = dict(os.environ, ITERS="400", SEED="7", ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
     run = subprocess.run([exe, str(tmp_path)] + files, capture_output=True, text=True, env=env, timeout=600)
     assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
