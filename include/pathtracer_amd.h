@@ -180,7 +180,10 @@ int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
  * overlaps the others' work; images do not depend on the setting.  Chains overlap only if HIP has
  * a hardware queue for each: the default is 4, or 8 / 16 when GPU_MAX_HW_QUEUES >= 8 / >= 16 is in
  * the environment (HIP reads it when its runtime starts; 16 is the measured optimum, more queues
- * than chains cost throughput).  No counterpart in the reference, whose scheduling is the Vulkan
+ * than chains cost throughput).  The library sets GPU_MAX_HW_QUEUES=16 itself when it is loaded with
+ * the variable unset, which takes effect if no HIP call has been made yet.  After a successful
+ * pt_set_chains, pt_last_error holds a warning text when chains exceeds the queues the variable
+ * allows, else an empty string.  No counterpart in the reference, whose scheduling is the Vulkan
  * driver's. */
 int pt_set_chains(pt_ctx* ctx, uint32_t chains);
 /* Up to `frames` (1..8) consecutive pt_trace calls share their kernel launches: the paths of all

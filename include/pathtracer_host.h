@@ -67,6 +67,10 @@ int pth_layer_set_submesh_transform(pth_layer* l, uint32_t submesh, const float*
 int pth_layer_drag_submesh_transform(pth_layer* l, uint32_t submesh, const float* column_major16);
 /* TextureCube{path = "...hdr"} (RayTracingLayer.cpp:50-54): load a Radiance image and make it the environment */
 int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face_size);
+/* m_SkyboxSettings + m_UpdateSkyBox (RayTracingLayer.h:88-89, sliders at RayTracingLayer.cpp:526-529): new Preetham
+ * parameters; the next on_update restarts the accumulation (RayTracingLayer.cpp:356-357) and, with use_as_environment,
+ * makes the Preetham cube (face_size texels per face; the reference uses 2048) the environment of the ray-tracing pass */
+int pth_layer_set_skybox_settings(pth_layer* l, float turbidity, float azimuth, float inclination, int use_as_environment, uint32_t face_size);
 /* m_DoPostProcessing / m_Exposure (RayTracingLayer.h:90-92, RayTracingLayer.cpp:522-524); on by default, 0.8 */
 int pth_layer_set_post_processing(pth_layer* l, int on, float exposure);
 int pth_layer_read_postprocessed(pth_layer* l, uint8_t* rgba8);   /* m_PostProcessingImage after the last on_render */

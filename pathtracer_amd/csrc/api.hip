@@ -11,6 +11,16 @@ namespace ptd {
 
 static thread_local std::string g_create_error;
 
+// A frame runs as up to 16 chains, each on a HIP stream that needs a hardware queue of its own; HIP gives a process 4
+// unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable when its runtime starts (its first API call).  When
+// the library is loaded before that (linked into the application, or dlopen'ed before any HIP call) and the variable
+// is unset, it asks for 16 here, so that a host application gets the full rate without a launcher script.
+static bool g_asked_for_queues = false;
+__attribute__((constructor)) static void ask_for_hardware_queues()
+{
+    if (!getenv("GPU_MAX_HW_QUEUES")) g_asked_for_queues = setenv("GPU_MAX_HW_QUEUES", "16", 0) == 0;
+}
+
 int set_error(pt_ctx* ctx, int code, const std::string& msg)
 {
     if (ctx) ctx->error = msg;
@@ -471,6 +481,11 @@ int pt_set_chains(pt_ctx* ctx, uint32_t chains)
     }
     ctx->chains = chains;
     ctx->main_dirty = true;
+    // not an error, but worth telling: chains that share a hardware queue run one after the other
+    uint32_t hwq = 4;
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = (uint32_t)atoi(e);
+    ctx->error = chains > hwq ? "warning: " + std::to_string(chains) + " chains but GPU_MAX_HW_QUEUES allows " + std::to_string(hwq) +
+                                " hardware queues; set GPU_MAX_HW_QUEUES >= chains before the HIP runtime starts" : std::string();
     return PT_OK;
 }
 

@@ -17,7 +17,7 @@ EXPORTS = [
     "pth_layer_set_viewport", "pth_layer_set_params", "pth_layer_set_accumulate", "pth_layer_set_camera_position",
     "pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render", "pth_layer_frame_index",
     "pth_layer_read_image", "pth_layer_read_accum", "pth_layer_ray_count", "pth_layer_last_error",
-    "pth_layer_set_submesh_transform", "pth_layer_drag_submesh_transform", "pth_layer_set_radiance_map", "pth_layer_set_post_processing", "pth_layer_read_postprocessed",
+    "pth_layer_set_submesh_transform", "pth_layer_drag_submesh_transform", "pth_layer_set_radiance_map", "pth_layer_set_skybox_settings", "pth_layer_set_post_processing", "pth_layer_read_postprocessed",
     "pth_hdr_load", "pth_pixels_free", "pth_ppm_write", "pth_image_load", "pth_image_free", "pth_mesh_load_textures",
 ]
 
@@ -74,6 +74,7 @@ def load_library():
     L.pth_layer_set_submesh_transform.argtypes = [vp, C.c_uint32, fp]
     L.pth_layer_drag_submesh_transform.argtypes = [vp, C.c_uint32, fp]
     L.pth_layer_set_radiance_map.argtypes = [vp, C.c_char_p, C.c_uint32]
+    L.pth_layer_set_skybox_settings.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_uint32]
     L.pth_layer_set_post_processing.argtypes = [vp, C.c_int, C.c_float]
     L.pth_layer_read_postprocessed.argtypes = [vp, C.POINTER(C.c_uint8)]
     L.pth_hdr_load.argtypes = [C.c_char_p, up, up, C.POINTER(fp), C.c_char_p, C.c_size_t]
@@ -251,6 +252,10 @@ class RayTracingLayer:
 
     def SetRadianceMap(self, hdr_path, face_size=1024):
         self._check(self.L.pth_layer_set_radiance_map(self.h, os.fsencode(hdr_path), face_size))
+
+    def SetSkyboxSettings(self, turbidity=3.14, azimuth=0.0, inclination=0.0, use_as_environment=False, face_size=2048):
+        """New Preetham parameters: the next OnUpdate restarts the accumulation and (optionally) re-renders the sky cube."""
+        self._check(self.L.pth_layer_set_skybox_settings(self.h, turbidity, azimuth, inclination, int(use_as_environment), face_size))
 
     def SetPostProcessing(self, on=True, exposure=0.8):
         self._check(self.L.pth_layer_set_post_processing(self.h, int(on), exposure))

@@ -315,7 +315,20 @@ void RayTracingLayer::MaterialsChanged()
 void RayTracingLayer::OnUpdate()
 {
     bool moved = m_Camera->Update();
-    if (!m_Accumulate || moved) m_SceneBuffer.FrameIndex = 1;   // RayTracingLayer.cpp:356-357
+    if (!m_Accumulate || moved || m_UpdateSkyBox) m_SceneBuffer.FrameIndex = 1;   // RayTracingLayer.cpp:356-357
+    if (m_UpdateSkyBox) {                                       // RayTracingLayer.cpp:366-380
+        if (m_SkyAsEnvironment)
+            m_Device->Check(pt_env_preetham(m_Device->Get(), m_SkyboxSettings[0], m_SkyboxSettings[1], m_SkyboxSettings[2], m_SkyFaceSize), "pt_env_preetham");
+        m_UpdateSkyBox = false;
+    }
+}
+
+void RayTracingLayer::SetSkyboxSettings(float turbidity, float azimuth, float inclination, bool useAsEnvironment, uint32_t faceSize)
+{
+    m_SkyboxSettings[0] = turbidity; m_SkyboxSettings[1] = azimuth; m_SkyboxSettings[2] = inclination;
+    m_SkyAsEnvironment = useAsEnvironment;
+    m_SkyFaceSize = faceSize;
+    m_UpdateSkyBox = true;
 }
 
 void RayTracingLayer::OnRender()

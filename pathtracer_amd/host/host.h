@@ -253,6 +253,11 @@ public:
     // refit: keep the hierarchy's topology (an object being dragged); otherwise the hierarchy is rebuilt, as the reference does
     void SetSubMeshTransform(uint32_t submesh, const Mat4& worldTransform, bool refit = false);
     void SetRadianceMap(const std::string& hdrPath, uint32_t faceSize = 1024);   // RayTracingLayer.cpp:50-54 (TextureCube of the engine)
+    // the sky sliders of RayTracingLayer.cpp:526-529: new Preetham parameters (turbidity, azimuth, inclination) mark the sky
+    // dirty; the next OnUpdate restarts the accumulation and runs the sky pass (RayTracingLayer.cpp:356-357,366-380).  The
+    // reference renders that cube but never binds it to the ray-tracing set (:258 binds the .hdr radiance map), so by
+    // default the pass is skipped here; with useAsEnvironment the Preetham cube becomes the environment the paths see.
+    void SetSkyboxSettings(float turbidity, float azimuth, float inclination, bool useAsEnvironment, uint32_t faceSize = 2048);
     void SetPostProcessing(bool on, float exposure) { m_DoPostProcessing = on; m_Exposure = exposure; }   // RayTracingLayer.cpp:522-524
     std::vector<uint8_t> ReadPostProcessed();                  // m_PostProcessingImage, RGBA8
     Ref<Camera> GetCamera() const { return m_Camera; }
@@ -277,6 +282,10 @@ private:
     SceneBuffer m_SceneBuffer;
     uint32_t m_ViewportWidth = 1, m_ViewportHeight = 1;
     bool m_Resized = true;
+    float m_SkyboxSettings[3] = {3.14f, 0.0f, 0.0f};           // RayTracingLayer.h:88
+    bool m_UpdateSkyBox = true;                                // RayTracingLayer.h:89
+    bool m_SkyAsEnvironment = false;
+    uint32_t m_SkyFaceSize = 2048;                             // RayTracingLayer.cpp:58-61
     bool m_DoPostProcessing = true;                            // RayTracingLayer.h:90
     float m_Exposure = 0.8f;                                   // RayTracingLayer.h:92
 };

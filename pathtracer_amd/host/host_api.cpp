@@ -196,6 +196,10 @@ int pth_layer_set_radiance_map(pth_layer* l, const char* hdr_path, uint32_t face
 {
     return guarded(l, [&] { l->layer->SetRadianceMap(hdr_path, face_size); });
 }
+int pth_layer_set_skybox_settings(pth_layer* l, float turbidity, float azimuth, float inclination, int use_as_environment, uint32_t face_size)
+{
+    return guarded(l, [&] { l->layer->SetSkyboxSettings(turbidity, azimuth, inclination, use_as_environment != 0, face_size); });
+}
 int pth_layer_set_post_processing(pth_layer* l, int on, float exposure) { return guarded(l, [&] { l->layer->SetPostProcessing(on != 0, exposure); }); }
 int pth_layer_read_postprocessed(pth_layer* l, uint8_t* rgba8)
 {

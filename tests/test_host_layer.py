@@ -244,6 +244,20 @@ def test_layer_frame_sequencing(tmp_path):
     src.set_material(0, words)
     layer.MaterialsChanged()
     assert layer.FrameIndex == 1
+    # a sky parameter change restarts the accumulation at the next update (m_UpdateSkyBox, RayTracingLayer.cpp:356-357)
+    layer.OnUpdate(); layer.OnRender()
+    layer.OnUpdate(); layer.OnRender()
+    assert layer.FrameIndex == 3
+    before = layer.ReadImage()
+    layer.SetSkyboxSettings(2.0, 1.1, 0.7, use_as_environment=True, face_size=64)
+    assert layer.FrameIndex == 3                 # dirty flag only; the reset happens in OnUpdate
+    layer.OnUpdate()
+    assert layer.FrameIndex == 1
+    layer.OnRender()
+    layer.OnUpdate()
+    assert layer.FrameIndex == 2                 # the flag was cleared by the update that used it
+    layer.OnRender()
+    assert not np.array_equal(layer.ReadImage(), before)     # the paths now see the Preetham sky
     layer.SetAccumulate(False)
     layer.OnUpdate(); layer.OnRender()
     layer.OnUpdate()
