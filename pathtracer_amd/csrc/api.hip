@@ -51,7 +51,7 @@ static void free_images(pt_ctx* c)
 {
     (void)dev_free(c->d_image_own); (void)dev_free(c->d_accum_own); (void)dev_free(c->d_primary); (void)dev_free(c->d_post);
     (void)dev_free(c->d_rayO[0]); (void)dev_free(c->d_rayO[1]); (void)dev_free(c->d_rayD[0]); (void)dev_free(c->d_rayD[1]);
-    (void)dev_free(c->d_hits); (void)dev_free(c->d_stC);
+    (void)dev_free(c->d_hits); (void)dev_free(c->d_hit_det); (void)dev_free(c->d_stC);
     for (int i = 0; i < 2; i++) { (void)dev_free(c->d_stA[i]); (void)dev_free(c->d_stB[i]); } (void)dev_free(c->d_partial);
     c->d_image = c->d_accum = nullptr;
     c->width = c->height = 0;
@@ -420,6 +420,7 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_stB[i], slots * 16));
     }
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_hits, slots * 16));
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_hit_det, slots * 4));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_stC, n * PT_MAX_BATCH * 16));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_partial, n * PT_MAX_BATCH * 16));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_image_own, 0, n * 16, ctx->stream));

@@ -70,6 +70,7 @@ struct pt_ctx {
     float4* d_rayO[2] = {nullptr, nullptr};
     float4* d_rayD[2] = {nullptr, nullptr};
     float4* d_hits = nullptr;
+    float* d_hit_det = nullptr;                // determinant of each hit: the barycentric weights are divided out by k_shade
     float4* d_stA[2] = {nullptr, nullptr};     // path state travels with the ray: per queue slot (throughput, seed)
     float4* d_stB[2] = {nullptr, nullptr};     // and (radiance, bounce | sample << 16)
     float4* d_stC = nullptr;                   // per path: colour of the pixel's finished samples

@@ -50,7 +50,10 @@ namespace ptd {
 #define PT_RAY_RESUME 2u
 #define PT_SUSPEND_STATE_WORDS 16   // a suspended traversal is 16 words of state followed by the stack (2 words per entry)
 #define PT_CUR_NONE 0x7FFFFFFFu   // s.cur when the stack ran empty; node indices are below, leaf references above
-#define PT_OWNER_BYTES (64 * PT_LEAF_MAX * 2)   // LDS bytes per wave for the triangle phase's work list (one uint16 per triangle)
+// LDS scratch per wave, used by one phase at a time: in a node step the node's eight child references, [slot][lane]
+// (a lane picks the reference of a sorted child with one LDS read instead of a tree of selects over eight registers);
+// in the triangle phase the work list (one uint16 per triangle, 64 * PT_LEAF_MAX of them)
+#define PT_SCRATCH_WORDS (8 * 64)
 
 struct HitRec {
     float t, u, v;
@@ -209,25 +212,19 @@ PT_DEV bool trav_pop(Trav& s, uint2* lds_stack, int stride, const uint2* ovf)
 
 PT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); }
 
-// child reference number `slot` (0..7) out of the eight held in registers
-PT_DEV uint32_t pick_child(uint4 c03, uint4 c47, uint32_t slot)
-{
-    uint32_t a = (slot & 4u) ? c47.x : c03.x, b = (slot & 4u) ? c47.y : c03.y;
-    uint32_t c = (slot & 4u) ? c47.z : c03.z, d = (slot & 4u) ? c47.w : c03.w;
-    uint32_t e = (slot & 2u) ? c : a, f = (slot & 2u) ? d : b;
-    return (slot & 1u) ? f : e;
-}
-
 #define PT_KEY_MISS 0x7f800000u
 
 // one internal node: decodes the eight quantised child boxes, slab-tests them, follows the nearest
 // hit child and stacks the others, farthest first.  A sort key is the entry distance with the
 // child's slot number in its three lowest mantissa bits, so the eight candidates are ordered with a
 // 19-comparator network of integer min/max.
-PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack, int stride, uint2* ovf)
+PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack, int stride, uint2* ovf, uint32_t* child_row)
 {
     const uint4* np = reinterpret_cast<const uint4*>(nodes + s.cur);
     uint4 hdr = np[0], c03 = np[1], c47 = np[2], qa = np[3], qb = np[4], qc = np[5];
+    // child_row points at this lane's column of the wave's scratch: reference of slot k at child_row[k * 64]
+    child_row[0 * 64] = c03.x; child_row[1 * 64] = c03.y; child_row[2 * 64] = c03.z; child_row[3 * 64] = c03.w;
+    child_row[4 * 64] = c47.x; child_row[5 * 64] = c47.y; child_row[6 * 64] = c47.z; child_row[7 * 64] = c47.w;
     // plane = origin + q * step  =>  t = q * (step * idir) + (origin * idir - o * idir -+ slack)
     float ox = u2f(hdr.x), oy = u2f(hdr.y), oz = u2f(hdr.z);
     float ax = u2f((hdr.w & 255u) << 23) * s.idx;
@@ -270,13 +267,31 @@ PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack
     PT_CE(2, 4) PT_CE(3, 5)
     PT_CE(1, 2) PT_CE(3, 4) PT_CE(5, 6)
 #undef PT_CE
+#ifdef PT_DUMMY_VALU
+    {   // experiment: extra independent VALU work per node step
+        uint32_t d0 = key[0], d1 = key[1];
+#pragma unroll
+        for (int k = 0; k < PT_DUMMY_VALU / 2; k++) {
+            asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(d0) : "v"(key[2]), "v"(key[3]));
+            asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(d1) : "v"(key[4]), "v"(key[5]));
+        }
+        asm volatile("" :: "v"(d0), "v"(d1));
+    }
+#endif
+#ifdef PT_DUMMY_LDS
+#pragma unroll
+    for (int k = 0; k < PT_DUMMY_LDS; k++) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"((uint32_t)(size_t)child_row), "v"(key[k & 7]), "n"((k & 7) * 256) : "memory");
+#endif
+#ifdef PT_DUMMY_SLEEP
+    __builtin_amdgcn_s_sleep(PT_DUMMY_SLEEP);
+#endif
     // farthest first, so the nearest is popped (or followed) first
     stack_reserve(s, lds_stack, stride, ovf, 7);
 #pragma unroll
     for (int j = 7; j >= 1; j--) {
-        if (key[j] < PT_KEY_MISS) PT_PUSH(pick_child(c03, c47, key[j] & 7u), u2f(key[j] & 0x7ffffff8u))
+        if (key[j] < PT_KEY_MISS) PT_PUSH(child_row[(key[j] & 7u) * 64], u2f(key[j] & 0x7ffffff8u))
     }
-    if (key[0] < PT_KEY_MISS) { s.cur = pick_child(c03, c47, key[0] & 7u); s.cur_key = u2f(key[0] & 0x7ffffff8u); return true; }
+    if (key[0] < PT_KEY_MISS) { s.cur = child_row[(key[0] & 7u) * 64]; s.cur_key = u2f(key[0] & 0x7ffffff8u); return true; }
     return trav_pop(s, lds_stack, stride, ovf);
 }
 
@@ -323,7 +338,7 @@ PT_DEV bool wins_tie(const TriRec* __restrict__ tris, uint32_t cand, uint32_t be
 // owner's ray fetched by lane permutes.  The owner then collects the distances of its items, keeps the closest
 // under the usual rules, and fetches that one's barycentric terms.  One call tests at most 64 items: lanes whose
 // items do not fit keep their leaf pending for the next call (returns whether this lane's leaf was tested).
-// `owner` is this wave's PT_OWNER_BYTES-byte LDS work list.  Must be called in wave-uniform control flow.
+// `owner` is this wave's LDS work list (the wave's scratch).  Must be called in wave-uniform control flow.
 template <bool STATS>
 PT_DEV bool leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, uint16_t* owner, uint32_t lane, uint32_t& stat_tris)
 {
@@ -382,6 +397,10 @@ PT_DEV bool leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, 
     return mine;
 }
 
+// The barycentric weights of the reported hit are best.u = bV / bdet and best.v = bW / bdet.  The traversal does not
+// divide: a finished ray hands (t, bV, bW, bdet, triangle) to emit(), and whoever consumes the hit divides, at full
+// lane occupancy (in the traversal loop a few lanes finish in almost every iteration, so the two correctly rounded
+// divisions would be issued for a handful of lanes each time).
 PT_DEV void finish_hit(Trav& s)
 {
     if (s.best.tri != 0xFFFFFFFFu) {
@@ -391,17 +410,19 @@ PT_DEV void finish_hit(Trav& s)
 }
 
 // Persistent-wave driver.  fetch(i, o, d, tmin, tmax) loads ray i of the queue and returns PT_RAY_* flags;
-// emit(i, hit) stores its result; suspend(i, record) hands ray i on with its traversal saved (see PT_CUT_LANES),
+// emit(i, traversal) stores its result (see finish_hit); suspend(i, record) hands ray i on with its traversal saved (see PT_CUT_LANES),
 // resume_record(i) is where a ray flagged PT_RAY_RESUME finds the traversal it was suspended with.
 // its result; *cursor hands out queue indices (must be 0 at launch), n = queue length.
 // lds_stack points at this lane's column: entry k is lds_stack[k * stride]; ovf points at this lane's
-// column of the wave's global spill area: entry k is ovf[k * 64]; owner is the wave's LDS work list.
+// column of the wave's global spill area: entry k is ovf[k * 64]; scratch is the wave's PT_SCRATCH_WORDS words of LDS.
 template <bool STATS, bool CUT, class Fetch, class Emit, class Suspend, class ResumeRecord>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
-                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint16_t* owner, Fetch fetch, Emit emit, Suspend suspend, ResumeRecord resume_record,
+                       uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint32_t* scratch, Fetch fetch, Emit emit, Suspend suspend, ResumeRecord resume_record,
                        uint32_t& stat_nodes, uint32_t& stat_tris, WaveStats* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
+    uint16_t* owner = reinterpret_cast<uint16_t*>(scratch);
+    uint32_t* child_row = scratch + lane;
     Trav s;
     bool has = false;
     bool exhausted = false;      // wave-uniform
@@ -433,7 +454,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
                     if (CUT && (flags & PT_RAY_RESUME)) trav_restore(s, resume_record(i), lds_stack, stride, ovf);
                     my = i;
                     ray_steps = 0;
-                    if (num_tris == 0) emit(my, s.best);
+                    if (num_tris == 0) emit(my, s);
                     else has = true;
                 }
             }
@@ -465,14 +486,14 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         if (STATS && has) { ray_steps++; ray_steps_max = max(ray_steps_max, ray_steps); }
         if (at_node) {
             if (STATS) stat_nodes++;
-            node_step(s, nodes, lds_stack, stride, ovf);
+            node_step(s, nodes, lds_stack, stride, ovf, child_row);
         }
         // a leaf goes to the pending slot and the lane walks on; with the slot taken the lane waits on the leaf
         if (has && s.cur > PT_CUR_NONE && s.pend == 0) {
             s.pend = s.cur;
             trav_pop(s, lds_stack, stride, ovf);
         }
-        if (has && s.cur == PT_CUR_NONE && s.pend == 0) { finish_hit(s); emit(my, s.best); has = false; }
+        if (has && s.cur == PT_CUR_NONE && s.pend == 0) { emit(my, s); has = false; }
         // triangle phase: once enough lanes hold a pending leaf, or nobody is left on a node
         bool has_pend = has && s.pend != 0;
         unsigned long long pendm = __ballot(has_pend);
@@ -487,7 +508,7 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
                     s.pend = s.cur;
                     trav_pop(s, lds_stack, stride, ovf);
                 }
-                if (s.cur == PT_CUR_NONE && s.pend == 0) { finish_hit(s); emit(my, s.best); has = false; }
+                if (s.cur == PT_CUR_NONE && s.pend == 0) { emit(my, s); has = false; }
             }
         }
     }

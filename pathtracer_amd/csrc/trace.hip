@@ -43,7 +43,8 @@ static constexpr uint32_t MISS = 0xFFFFFFFFu;
 struct Queues {
     float4* rayO_in; float4* rayD_in;
     float4* rayO_out; float4* rayD_out;
-    float4* hits;
+    float4* hits;           // per queue slot (t, V, W, triangle); barycentric u = V / hit_det, v = W / hit_det
+    const float* hit_det;
     float4* stA_in; float4* stB_in;     // path state of the queued rays, by queue slot like the rays
     float4* stA_out; float4* stB_out;
     float4* stC;                        // per path
@@ -190,6 +191,7 @@ struct ExtendArgs {
     const float4* stA; const float4* stB;       // path state by queue slot: a suspended ray takes its state along
     float4* next_stA; float4* next_stB;
     float4* hits;
+    float* hit_det;
     uint2* spill;
 };
 
@@ -197,7 +199,7 @@ template <bool STATS, bool CUT>
 __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneView sc, ExtendArgs a, unsigned long long* stats, unsigned long long* wave_trace)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
-    __shared__ uint16_t owner[PT_OWNER_BYTES / 2];
+    __shared__ uint32_t scratch[PT_SCRATCH_WORDS];
     const uint32_t ls = blockIdx.x % a.nshards;
     const uint32_t n = a.counts[ls];
     const uint32_t base = (a.shard0 + ls) * a.shard_cap;
@@ -212,7 +214,11 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
         uint32_t w = f2u(rd.w);
         return ((w & RAY_LAG_MASK) < a.max_lag ? PT_RAY_CUTTABLE : 0u) | ((w & RAY_RESUMES) ? PT_RAY_RESUME : 0u);
     };
-    auto emit = [&](uint32_t i, const HitRec& h) { a.hits[base + i] = make_float4(h.t, h.u, h.v, u2f(h.tri)); };
+    // the hit goes out undivided: (t, V, W, triangle) and the determinant; k_shade divides u = V / det, v = W / det
+    auto emit = [&](uint32_t i, const Trav& s) {
+        a.hits[base + i] = make_float4(s.best.t, s.bV, s.bW, u2f(s.best.tri));
+        a.hit_det[base + i] = s.bdet;
+    };
     auto suspend = [&](uint32_t i, const Trav& s, const uint2* lds_stack, int stride, const uint2* ovf) {
         // called by all lanes that suspend, inside one branch: one queue slot each at the front of the next round
         unsigned long long m = __ballot(true);
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
     };
     auto resume_record = [&](uint32_t i) { return a.susp_in + ((size_t)ls * a.susp_cap + i) * a.susp_words; };
     trace_wave<STATS, CUT>(sc.nodes, sc.tris, sc.num_tris, n, &a.cursors[ls], stack + threadIdx.x, EXT_BLOCK,
-                           a.spill + (size_t)blockIdx.x * (a.stack_entries * 64) + threadIdx.x, owner, fetch, emit, suspend, resume_record, sn, st, STATS ? &ws : nullptr);
+                           a.spill + (size_t)blockIdx.x * (a.stack_entries * 64) + threadIdx.x, scratch, fetch, emit, suspend, resume_record, sn, st, STATS ? &ws : nullptr);
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
@@ -484,7 +490,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams
                 if (bounce == 0 && sample == 0 && pixel / npix + 1u == P.nframes) q.primary[pixel % npix] = make_uint2(st.submesh, st.prim);
                 Surf s;
                 v3 emission, N;
-                fetch_surface(sc, st, h.y, h.z, d, s, emission, N);
+                const float det = q.hit_det[slot];
+                fetch_surface(sc, st, fdiv(h.y, det), fdiv(h.z, det), d, s, emission, N);
                 rad = rad + emission * thr;                           // RayGen.glsl:137
                 bool last_bounce = bounce + 1 >= P.max_bounces;
                 if (last_bounce && sample + 1 >= P.spp) {
@@ -666,7 +673,8 @@ int launch_trace(pt_ctx* ctx)
     const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? 48u : 40u);
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
-    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, max_blocks, nframes);
+    static const uint32_t shade_override = getenv("PT_SHADE_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("PT_SHADE_BLOCKS_PER_CU")) : 0u;
+    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, (uint32_t)ctx->num_cus * (shade_override ? shade_override : 8u), nframes);
     // a chain's share of the spill area and of the suspension records is laid out for a full batch, so that a
     // short batch launched while a full one is still running stays inside its own chain's share
     const uint32_t ext_blocks_max = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, PT_MAX_BATCH);
@@ -723,6 +731,7 @@ int launch_trace(pt_ctx* ctx)
         PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
         Queues q;
         q.hits = ctx->d_hits;
+        q.hit_det = ctx->d_hit_det;
         q.stC = ctx->d_stC;
         q.counts = counts;
         q.shard0 = c * spc; q.nshards = spc;
@@ -764,6 +773,7 @@ int launch_trace(pt_ctx* ctx)
             ea.stA = ctx->d_stA[in]; ea.stB = ctx->d_stB[in];
             ea.next_stA = ctx->d_stA[out]; ea.next_stB = ctx->d_stB[out];
             ea.hits = ctx->d_hits;
+            ea.hit_det = ctx->d_hit_det;
             ea.spill = spill;
             unsigned long long* wt = wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr;
             if (counting && ea.next_counts) k_extend<true, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
@@ -809,11 +819,11 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
                                                                 uint32_t* __restrict__ out, uint2* spill, uint32_t stack_entries, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
-    __shared__ uint16_t owner[PT_OWNER_BYTES / 2];
+    __shared__ uint32_t scratch[PT_SCRATCH_WORDS];
     uint32_t sn = 0, st = 0;
     trace_wave<true, false>(
         sc.nodes, sc.tris, sc.num_tris, n, cursor, stack + threadIdx.x, EXT_BLOCK,
-        spill + (size_t)blockIdx.x * (stack_entries * 64) + threadIdx.x, owner,
+        spill + (size_t)blockIdx.x * (stack_entries * 64) + threadIdx.x, scratch,
         [&](uint32_t i, v3& o, v3& d, float& tn, float& tx) {
             float4 ro = rays[2 * i], rd = rays[2 * i + 1];
             o = V3(ro.x, ro.y, ro.z);
@@ -822,7 +832,10 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
             tx = rd.w;
             return 0u;
         },
-        [&](uint32_t i, const HitRec& h) {
+        [&](uint32_t i, const Trav& s) {
+            Trav fin = s;
+            finish_hit(fin);
+            const HitRec& h = fin.best;
             uint32_t* o = out + (size_t)i * 5;
             if (h.tri == MISS) { o[0] = f2u(h.t); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }   // h.t is still tmax
             else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = sc.tris[h.tri].submesh; o[4] = sc.tris[h.tri].prim; }
