@@ -47,6 +47,35 @@ def host_threads():
     return max(1, min(16, n))
 
 
+def gltf_workload(path, width, height, scale, cam_text):
+    """A glTF file of the user's own (the reference selects its model by path, RayTracingLayer.cpp:27-32): imported by the
+    C++ host layer with its PNG / JPEG textures; layer transform = uniform scale (the reference uses 0.1 for its Cornell
+    box, RayTracingLayer.cpp:34).  Camera: "ex,ey,ez,tx,ty,tz[,fov_y]" (eye, target), default a view of the scene's box."""
+    import numpy as np
+    from pathtracer_amd import camera, host
+    src = host.MeshSource(path)
+    ntex = src.load_textures()
+    sc = src.scene_data(np.diag([scale, scale, scale, 1.0]), with_textures=True)
+    if cam_text:
+        v = [float(x) for x in cam_text.split(",")]
+        eye, target, fov = v[0:3], v[3:6], (v[6] if len(v) > 6 else 45.0)
+    else:
+        pts = []
+        for s_, xf in zip(sc.submeshes, sc.xforms):
+            n = int(s_[1])
+            m = xf.reshape(3, 4)
+            p = sc.vertices[n:n + 8192:64, 0:3] if len(sc.vertices) > n else sc.vertices[:1, 0:3]
+            pts.append(p @ m[:, :3].T + m[:, 3])
+        pts = np.concatenate(pts)
+        lo, hi = pts.min(0), pts.max(0)
+        c, ext = (lo + hi) / 2, float((hi - lo).max())
+        eye, target, fov = (c + np.array([0.35, 0.25, 1.0]) * ext * 0.9).tolist(), c.tolist(), 45.0
+    near = max(1e-4, 1e-4 * float(np.linalg.norm(np.subtract(eye, target))))
+    cam = camera.camera_buffer(camera.look_at(eye, target), camera.perspective(fov, width / height, near, near * 1e5))
+    return sc, cam, "%s (%d tris, %d submeshes, %d materials, %d textures), scale %g" % (
+        os.path.basename(path), sc.num_triangles, len(sc.submeshes), len(sc.materials), ntex, scale)
+
+
 def make_workload(name, width, height, detail=1.0):
     from pathtracer_amd import camera, procedural
     from pathtracer_amd.scene import SceneData
@@ -75,6 +104,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--build-flags", type=int, default=0)
     ap.add_argument("--detail", type=float, default=1.0, help="tessellation scale of the procedural scenes (1 = the benchmark scene)")
+    ap.add_argument("--gltf", default=None, help="benchmark this glTF file (with its textures) instead of a built-in workload")
+    ap.add_argument("--scale", type=float, default=1.0, help="layer transform of --gltf: uniform scale")
+    ap.add_argument("--camera", default=None, help='camera of --gltf: "ex,ey,ez,tx,ty,tz[,fov_y]"')
     args = ap.parse_args()
 
     import numpy as np
@@ -106,7 +138,11 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    scene, cam, workload_text = make_workload(args.workload, args.width, args.height, args.detail)
+    if args.gltf:
+        scene, cam, workload_text = gltf_workload(args.gltf, args.width, args.height, args.scale, args.camera)
+        args.workload = "gltf"
+    else:
+        scene, cam, workload_text = make_workload(args.workload, args.width, args.height, args.detail)
     params = Params.reference(spp_per_frame=1, max_bounces=args.bounces)
     b = Backend(local_rank)
     b.scene_upload(scene)

@@ -36,6 +36,9 @@ const char* pth_mesh_texture_uri(pth_mesh* m, uint32_t i);
 /* sampler state of glTF image i as PT_TEX_* flags (from the sampler of the first glTF texture that uses the image) */
 uint32_t pth_mesh_texture_sampler(pth_mesh* m, uint32_t i);
 /* supplies decoded RGBA8 texels for glTF image i (this layer has no JPEG/PNG decoder) */
+/* the decoded texels of image i (after pth_mesh_load_textures or pth_mesh_set_texture): size always; texels when rgba8 != NULL
+ * (width*height*4 bytes; 0 x 0 = not decoded) */
+int pth_mesh_get_texture(pth_mesh* m, uint32_t i, uint32_t* width, uint32_t* height, uint8_t* rgba8);
 int pth_mesh_set_texture(pth_mesh* m, uint32_t i, uint32_t width, uint32_t height, const uint8_t* rgba8);
 /* edits one 22-word material record (the ImGui material sliders, RayTracingLayer.cpp:536-564) */
 int pth_mesh_set_material(pth_mesh* m, uint32_t i, const float* words22);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpt_host.so")
 
 EXPORTS = [
     "pth_mesh_load", "pth_mesh_free", "pth_mesh_counts", "pth_mesh_tables", "pth_mesh_submesh_name", "pth_mesh_texture_uri", "pth_mesh_texture_sampler",
-    "pth_mesh_set_texture", "pth_mesh_set_material", "pth_camera_matrices", "pth_layer_create", "pth_layer_destroy",
+    "pth_mesh_get_texture", "pth_mesh_set_texture", "pth_mesh_set_material", "pth_camera_matrices", "pth_layer_create", "pth_layer_destroy",
     "pth_layer_set_viewport", "pth_layer_set_params", "pth_layer_set_accumulate", "pth_layer_set_camera_position",
     "pth_layer_materials_changed", "pth_layer_on_update", "pth_layer_on_render", "pth_layer_frame_index",
     "pth_layer_read_image", "pth_layer_read_accum", "pth_layer_ray_count", "pth_layer_last_error",
@@ -51,6 +51,7 @@ def load_library():
     L.pth_mesh_texture_uri.restype = C.c_char_p
     L.pth_mesh_texture_sampler.argtypes = [vp, C.c_uint32]
     L.pth_mesh_texture_sampler.restype = C.c_uint32
+    L.pth_mesh_get_texture.argtypes = [vp, C.c_uint32, up, up, C.POINTER(C.c_uint8)]
     L.pth_mesh_set_texture.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
     L.pth_mesh_set_material.argtypes = [vp, C.c_uint32, fp]
     L.pth_camera_matrices.argtypes = [C.POINTER(CameraSpec), C.c_uint32, C.c_uint32, fp]
@@ -155,8 +156,9 @@ class MeshSource:
         m = np.ascontiguousarray(words, np.float32)
         assert m.size == 22 and self.L.pth_mesh_set_material(self.h, i, _fp(m)) == 0
 
-    def scene_data(self, layer_transform=None):
-        """The tables in pt_scene_desc layout; layer_transform is a 4x4 (row-major numpy) matrix."""
+    def scene_data(self, layer_transform=None, with_textures=False):
+        """The tables in pt_scene_desc layout; layer_transform is a 4x4 (row-major numpy) matrix.  with_textures: the
+        decoded images too (load_textures() first); otherwise the materials' map indices are cleared."""
         nv, ni, ns, nm, nt = self.counts()
         vertices = np.empty((nv, 12), np.float32)
         indices = np.empty(ni, np.uint32)
@@ -171,7 +173,23 @@ class MeshSource:
         self.L.pth_mesh_tables(self.h, None if lt is None else _fp(lt), _fp(vertices), indices.ctypes.data_as(up),
                                submeshes.ctypes.data_as(up), counts.ctypes.data_as(up), _fp(xforms), _fp(materials))
         names = [self.L.pth_mesh_submesh_name(self.h, i).decode() for i in range(ns)]
-        return SceneData(vertices, indices, submeshes, counts, xforms, materials, names=names)
+        sc = SceneData(vertices, indices, submeshes, counts, xforms, materials, names=names)
+        if with_textures:
+            # the decoded images with their sampler state; materials keep their map indices only if every image is there
+            tex = []
+            for i in range(nt):
+                w, h = C.c_uint32(), C.c_uint32()
+                self.L.pth_mesh_get_texture(self.h, i, C.byref(w), C.byref(h), None)
+                if w.value == 0 or h.value == 0:
+                    raise RuntimeError("texture %d (%s) has not been decoded: call load_textures() first" % (i, self.texture_uris()[i]))
+                t = np.empty((h.value, w.value, 4), np.uint8)
+                self.L.pth_mesh_get_texture(self.h, i, C.byref(w), C.byref(h), t.ctypes.data_as(C.POINTER(C.c_uint8)))
+                tex.append(t)
+            sc.textures = tex
+            sc.texture_flags = self.texture_samplers()
+        else:
+            sc.materials.view(np.int32)[:, 10:13] = -1
+        return sc
 
 
 class RayTracingLayer:

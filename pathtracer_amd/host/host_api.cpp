@@ -104,6 +104,15 @@ const char* pth_mesh_submesh_name(pth_mesh* m, uint32_t i) { return m->source->G
 const char* pth_mesh_texture_uri(pth_mesh* m, uint32_t i) { return m->source->GetTextures().at(i).Uri.c_str(); }
 uint32_t pth_mesh_texture_sampler(pth_mesh* m, uint32_t i) { return i < m->source->GetTextures().size() ? m->source->GetTextures()[i].SamplerFlags : 0u; }
 
+int pth_mesh_get_texture(pth_mesh* m, uint32_t i, uint32_t* w, uint32_t* h, uint8_t* rgba8)
+{
+    if (i >= m->source->GetTextures().size() || !w || !h) return PT_ERR_INVALID;
+    const TextureData& t = m->source->GetTextures()[i];
+    *w = t.Width; *h = t.Height;
+    if (rgba8 && !t.RGBA8.empty()) std::memcpy(rgba8, t.RGBA8.data(), t.RGBA8.size());
+    return PT_OK;
+}
+
 int pth_mesh_set_texture(pth_mesh* m, uint32_t i, uint32_t w, uint32_t h, const uint8_t* rgba8)
 {
     if (i >= m->source->GetTextures().size() || !w || !h || !rgba8) return PT_ERR_INVALID;

@@ -461,6 +461,80 @@ def test_textured_reference_asset_at_1080p_64_frames(backend):
     assert not np.array_equal(backend.read_accum(), untextured)
 
 
+def _export_gltf(sc, folder):
+    """Writes a SceneData as .gltf + .bin + PNG files (one node per submesh, its 3x4 matrix as the node matrix)."""
+    import json
+    from PIL import Image
+    blob = bytearray()
+    views, accessors, meshes, nodes = [], [], [], []
+
+    def add(arr, ctype, atype, target=None):
+        while len(blob) % 4:
+            blob.append(0)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": arr.nbytes})
+        blob.extend(arr.tobytes())
+        acc = {"bufferView": len(views) - 1, "componentType": ctype, "count": len(arr), "type": atype}
+        if atype == "VEC3" and target == "pos":
+            acc["min"], acc["max"] = arr.min(0).tolist(), arr.max(0).tolist()
+        accessors.append(acc)
+        return len(accessors) - 1
+    for i, (sub, cnt, xf) in enumerate(zip(sc.submeshes, sc.index_counts, sc.xforms)):
+        vo, io, mat = int(sub[1]), int(sub[2]), int(sub[3])
+        idx = sc.indices[io:io + int(cnt)]
+        nv = int(idx.max()) + 1
+        v = sc.vertices[vo:vo + nv]
+        prim = {"attributes": {"POSITION": add(np.ascontiguousarray(v[:, 0:3]), 5126, "VEC3", "pos"), "TEXCOORD_0": add(np.ascontiguousarray(v[:, 3:5]), 5126, "VEC2"),
+                               "NORMAL": add(np.ascontiguousarray(v[:, 5:8]), 5126, "VEC3"), "TANGENT": add(np.ascontiguousarray(v[:, 8:12]), 5126, "VEC4")},
+                "indices": add(np.ascontiguousarray(idx, np.uint32), 5125, "SCALAR"), "material": mat}
+        meshes.append({"primitives": [prim]})
+        m = np.eye(4)
+        m[:3, :] = xf.reshape(3, 4)
+        nodes.append({"mesh": i, "name": sc.names[i], "matrix": m.T.reshape(-1).tolist()})
+    mats = []
+    for w in sc.materials:
+        wi = w.view(np.int32)
+        pbr = {"baseColorFactor": [float(w[0]), float(w[1]), float(w[2]), 1.0], "metallicFactor": float(w[3]), "roughnessFactor": float(w[4])}
+        if wi[10] >= 0:
+            pbr["baseColorTexture"] = {"index": int(wi[10])}
+        if wi[11] >= 0:
+            pbr["metallicRoughnessTexture"] = {"index": int(wi[11])}
+        mats.append({"pbrMetallicRoughness": pbr, "emissiveFactor": [float(w[5]), float(w[6]), float(w[7])],
+                     "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": float(w[8])}, "KHR_materials_ior": {"ior": float(w[21])}}})
+    images = []
+    for i, t in enumerate(sc.textures):
+        Image.fromarray(t, "RGBA").save(os.path.join(folder, "tex%d.png" % i))
+        images.append({"uri": "tex%d.png" % i})
+    g = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": list(range(len(nodes)))}], "nodes": nodes, "meshes": meshes, "materials": mats,
+         "accessors": accessors, "bufferViews": views, "buffers": [{"uri": "scene.bin", "byteLength": len(blob)}],
+         "images": images, "textures": [{"source": i, "sampler": 0} for i in range(len(images))], "samplers": [{}]}
+    open(os.path.join(folder, "scene.bin"), "wb").write(bytes(blob))
+    path = os.path.join(folder, "scene.gltf")
+    json.dump(g, open(path, "w"))
+    return path
+
+
+def test_bench_workload_from_a_gltf_file(backend, tmp_path):
+    """bench.py --gltf: a user's own model by path (RayTracingLayer.cpp:27-32), imported with its textures by the C++ host layer.
+    The textured fixture goes out as .gltf + .bin + PNG, comes back through the same code bench.py runs, and renders bit for bit
+    like the fixture itself."""
+    pytest.importorskip("PIL.Image")
+    import bench
+    sc = SceneData.load(os.path.join(GOLDEN, "suzanne_scene.npz"))
+    path = _export_gltf(sc, str(tmp_path))
+    W, H = 160, 90
+    got, cam, text = bench.gltf_workload(path, W, H, 1.0, "0.9,0.4,2.5,0,-0.02,0")
+    assert "3936 tris" in text and "2 textures" in text
+    assert np.array_equal(got.vertices, sc.vertices) and np.array_equal(got.indices, sc.indices) and np.array_equal(got.xforms, sc.xforms)
+    assert np.array_equal(bits(got.materials), bits(sc.materials)) and all(np.array_equal(a, b) for a, b in zip(got.textures, sc.textures))
+    o, rays = render_pair(backend, got, cam, W, H, (1, 2, 3), spp_per_frame=1, max_bounces=6)
+    assert_same_frame(backend, o, rays)
+    assert (backend.read_primary_ids()[..., 0] != M32).mean() > 0.2
+    # the default camera frames the model
+    _, cam2, _ = bench.gltf_workload(path, W, H, 1.0, None)
+    o, rays = render_pair(backend, got, cam2, W, H, (1,), upload=False, spp_per_frame=1, max_bounces=1)
+    assert (backend.read_primary_ids()[..., 0] != M32).mean() > 0.05
+
+
 def test_russian_roulette_option(backend, cornell, cameras):
     o, rays = render_pair(backend, cornell, cameras["96x64"], 96, 64, (1, 2), spp_per_frame=2, max_bounces=12, rr_depth=2)
     assert_same_frame(backend, o, rays)

@@ -183,6 +183,22 @@ def test_gltf_import_reference_assets(rel):
 
 
 @pytest.mark.skipif(not have_ref, reason="reference assets are only mounted in the authoring container")
+def test_suzanne_with_textures_equals_the_committed_fixture():
+    """C++ import + C++ PNG decoder against the fixture minted by the Python reader + Pillow: tables, texels, sampler flags."""
+    from pathtracer_amd.scene import SceneData
+    src = host.MeshSource(os.path.join(REF_MODELS, "Suzanne/glTF/Suzanne.gltf"))
+    with pytest.raises(RuntimeError):
+        src.scene_data(with_textures=True)            # not decoded yet
+    assert src.load_textures() == 2
+    got = src.scene_data(with_textures=True)
+    want = SceneData.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "suzanne_scene.npz"))
+    assert_same_scene(got, want)
+    assert got.texture_flags == want.texture_flags and len(got.textures) == 2
+    assert all(np.array_equal(a, b) for a, b in zip(got.textures, want.textures))
+    assert (src.scene_data().materials.view(np.int32)[:, 10:13] == -1).all()
+
+
+@pytest.mark.skipif(not have_ref, reason="reference assets are only mounted in the authoring container")
 def test_cornell_fixture_is_the_host_loader_output(cornell):
     got = host.MeshSource(os.path.join(REF_MODELS, "CornellBox.gltf")).scene_data(np.diag([0.1, 0.1, 0.1, 1.0]))
     assert_same_scene(got, cornell)
