@@ -84,6 +84,11 @@ def make_workload(name, width, height, detail=1.0):
         return sc, procedural.sponza_camera(width, height), \
             "procedural Sponza-class atrium (%d tris, %d submeshes, 25 full-Disney materials; Sponza.bin is absent from the reference)" % (
                 sc.num_triangles, len(sc.submeshes))
+    if name == "sponza_like":
+        sc = procedural.sponza_class(detail=detail, layout="sponza", textures=True)
+        return sc, procedural.sponza_camera(width, height), \
+            "procedural Sponza-like atrium: large wall / floor / slab quads and long thin trims beside finely tessellated detail, %d tris, %d submeshes, " \
+            "25 full-Disney materials, %d textures of 512x512 (Sponza.bin is absent from the reference)" % (sc.num_triangles, len(sc.submeshes), len(sc.textures))
     if name == "bistro_class":
         return procedural.bistro_class(), procedural.bistro_camera(width, height), "procedural Bistro-class street (~3M tris)"
     if name == "cornell":

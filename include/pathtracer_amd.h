@@ -83,6 +83,7 @@ typedef struct pt_accel_stats {
     uint32_t num_leaves;
     float build_ms;            /* device time of the build kernels */
     float sah_cost;            /* surface-area-heuristic cost of the built hierarchy */
+    uint32_t num_references;   /* triangle records in the leaves: num_triangles, or more when long thin triangles were split */
 } pt_accel_stats;
 
 /* per-kernel device time of the frames traced since the previous read-out (HIP events on the
@@ -115,6 +116,8 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* scene);
  * that replaces the driver's BLAS/TLAS (binding 0).  flags: PT_BUILD_* below. */
 #define PT_BUILD_DEFAULT 0u
 #define PT_BUILD_LBVH 1u       /* Morton-order hierarchy only (no agglomerative refinement) */
+#define PT_BUILD_NO_SPLIT 2u   /* every triangle is entered once; by default large triangles whose boxes are mostly empty are
+                                * entered once per cell they pass through (same hits, tighter boxes) */
 int pt_build_accel(pt_ctx* ctx, uint32_t flags, pt_accel_stats* stats);
 /* AccelerationStructure::UpdateMaterialData() (RayTracingLayer.cpp:621). */
 int pt_update_materials(pt_ctx* ctx, const float* materials, uint32_t num_materials);
@@ -237,7 +240,7 @@ int pt_debug_disney_sample(pt_ctx* ctx, uint32_t n, const float* surf, const flo
                            uint32_t* seeds, float* f, float* L, float* pdf);
 int pt_debug_disney_eval(pt_ctx* ctx, uint32_t n, const float* surf, const float* V, const float* N,
                          const float* L, float* f, float* pdf);
-/* copies the built hierarchy to the host: nodes = num_nodes*32 words, tris = num_triangles*12 words */
+/* copies the built hierarchy to the host: nodes = num_nodes*32 words, tris = num_references*12 words */
 int pt_debug_read_bvh(pt_ctx* ctx, uint32_t* nodes, uint32_t* tris);
 
 #ifdef __cplusplus

@@ -31,7 +31,7 @@ class BackendError(RuntimeError):
 
 class AccelStats(C.Structure):
     _fields_ = [("num_triangles", C.c_uint32), ("num_nodes", C.c_uint32), ("max_depth", C.c_uint32),
-                ("num_leaves", C.c_uint32), ("build_ms", C.c_float), ("sah_cost", C.c_float)]
+                ("num_leaves", C.c_uint32), ("build_ms", C.c_float), ("sah_cost", C.c_float), ("num_references", C.c_uint32)]
 
 
 class TraceTiming(C.Structure):
@@ -308,6 +308,6 @@ class Backend:
     def debug_read_bvh(self):
         st = self.accel
         nodes = np.empty((st.num_nodes, 32), np.uint32)
-        tris = np.empty((st.num_triangles, 12), np.uint32)
+        tris = np.empty((st.num_references, 12), np.uint32)
         self._check(self.lib.pt_debug_read_bvh(self.h, _up(nodes), _up(tris)))
         return nodes, tris

@@ -722,7 +722,7 @@ int pt_debug_read_bvh(pt_ctx* ctx, uint32_t* nodes, uint32_t* tris)
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "pt_debug_read_bvh: hierarchy missing");
     if (nodes && ctx->num_nodes) PT_HIP(ctx, hipMemcpyAsync(nodes, ctx->d_nodes, (size_t)ctx->num_nodes * 128, hipMemcpyDeviceToHost, ctx->stream));
-    if (tris && ctx->num_tris) PT_HIP(ctx, hipMemcpyAsync(tris, ctx->d_tris, (size_t)ctx->num_tris * 48, hipMemcpyDeviceToHost, ctx->stream));
+    if (tris && ctx->num_refs) PT_HIP(ctx, hipMemcpyAsync(tris, ctx->d_tris, (size_t)ctx->num_refs * 48, hipMemcpyDeviceToHost, ctx->stream));
     PT_SYNC(ctx);
     return PT_OK;
 }

@@ -4,6 +4,7 @@
 //
 // Pipeline (all on the context's stream):
 //   1. k_world_tris   every submesh triangle -> world space (object-to-world 3x4), its box, scene bounds
+//   1b. k_split       long thin triangles whose boxes are mostly empty are entered once per cell they pass through
 //   2. k_morton       63-bit Morton code of the box centre
 //   3. radix sort     (rocPRIM via hipcub) of (code, triangle)
 //   4. binary hierarchy, one of
@@ -115,6 +116,126 @@ __global__ void k_world_tris(uint32_t n, uint32_t ns, const uint32_t* __restrict
             }
         }
     }
+}
+
+// ---- triangle splitting -------------------------------------------------------------------------------------------
+// A long thin triangle that runs diagonally through the scene has a box that is almost empty, and every ray that
+// crosses the box pays for it.  Such a triangle is entered into the hierarchy several times: its box is cut into
+// cubic cells (an eighth of its longest side, a quarter if that gives more than PT_SPLIT_MAX pieces) and every cell the
+// triangle actually passes through becomes a reference of its own, bounded by the part of the triangle inside the
+// cell.  All references carry the same triangle record, so hits (t, barycentrics, submesh, primitive) do not change.
+// A triangle is split when its box is large (more than 1/4096 of the scene's box area) and wasteful (more than 2.5
+// times the two-sided area of the triangle: an axis-aligned right triangle has 2).
+#define PT_SPLIT_MAX 64u
+
+// bounds of the part of triangle (a, b, c) inside the box [clo, chi]; false if there is none
+__device__ bool clip_bounds(v3 a, v3 b, v3 c, const float* clo, const float* chi, float* olo, float* ohi)
+{
+    float px[2][10][3];
+    int np = 3, cur = 0;
+    px[0][0][0] = a.x; px[0][0][1] = a.y; px[0][0][2] = a.z;
+    px[0][1][0] = b.x; px[0][1][1] = b.y; px[0][1][2] = b.z;
+    px[0][2][0] = c.x; px[0][2][1] = c.y; px[0][2][2] = c.z;
+    for (int plane = 0; plane < 6 && np > 0; plane++) {
+        const int ax = plane >> 1;
+        const bool upper = plane & 1;
+        const float lim = upper ? chi[ax] : clo[ax];
+        int nq = 0;
+        float (*in)[3] = px[cur];
+        float (*out)[3] = px[cur ^ 1];
+        for (int i = 0; i < np; i++) {
+            const float* p = in[i];
+            const float* q = in[(i + 1) % np];
+            const bool pin = upper ? p[ax] <= lim : p[ax] >= lim;
+            const bool qin = upper ? q[ax] <= lim : q[ax] >= lim;
+            if (pin) { out[nq][0] = p[0]; out[nq][1] = p[1]; out[nq][2] = p[2]; nq++; }
+            if (pin != qin) {
+                float t = (lim - p[ax]) / (q[ax] - p[ax]);
+                for (int k = 0; k < 3; k++) out[nq][k] = k == ax ? lim : p[k] + t * (q[k] - p[k]);
+                nq++;
+            }
+        }
+        np = nq;
+        cur ^= 1;
+    }
+    if (np == 0) return false;
+    for (int k = 0; k < 3; k++) { olo[k] = 3.4028235e38f; ohi[k] = -3.4028235e38f; }
+    for (int i = 0; i < np; i++)
+        for (int k = 0; k < 3; k++) {
+            olo[k] = fminf(olo[k], px[cur][i][k]);
+            ohi[k] = fmaxf(ohi[k], px[cur][i][k]);
+        }
+    // the clipped vertices carry rounding; the part can neither leave the cell nor the triangle's own box
+    for (int k = 0; k < 3; k++) { olo[k] = fmaxf(olo[k], clo[k]); ohi[k] = fminf(ohi[k], chi[k]); }
+    return true;
+}
+
+// WRITE = false: counts[g] = references of triangle g.  WRITE = true: writes them at offsets[g].
+template <bool WRITE>
+__global__ void k_split(uint32_t n, const TriRec* __restrict__ tris, const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                        const int* __restrict__ bounds, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                        TriRec* __restrict__ out_tris, float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const TriRec t = tris[g];
+    const float4 lo4 = tlo[g], hi4 = thi[g];
+    const float lo[3] = {lo4.x, lo4.y, lo4.z}, hi[3] = {hi4.x, hi4.y, hi4.z};
+    uint32_t w = WRITE ? offsets[g] : 0u;
+    auto whole = [&]() {
+        if (WRITE) { out_tris[w] = t; out_lo[w] = lo4; out_hi[w] = hi4; }
+        else counts[g] = 1u;
+    };
+    if (!(lo[0] <= hi[0])) { whole(); return; }                   // the empty box of a triangle that cannot be hit
+    const float e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    const float sa = 2.0f * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+    const float sx = ord2f(bounds[3]) - ord2f(bounds[0]), sy = ord2f(bounds[4]) - ord2f(bounds[1]), sz = ord2f(bounds[5]) - ord2f(bounds[2]);
+    const float scene_sa = 2.0f * (sx * sy + sy * sz + sz * sx);
+    const v3 a = V3(t.v0x, t.v0y, t.v0z), b = V3(t.v1x, t.v1y, t.v1z), c = V3(t.v2x, t.v2y, t.v2z);
+    const v3 cr = cross(b - a, c - a);
+    const float two_sided = sqrtf(dot(cr, cr));                    // 2 * (|cross| / 2)
+    if (!(sa > scene_sa * (1.0f / 4096.0f)) || !(sa > 2.5f * two_sided)) { whole(); return; }
+    const float emax = fmaxf(fmaxf(e[0], e[1]), e[2]);
+    // visits the cells of a (emax / div) grid over the box that the triangle passes through; returns how many
+    auto cells = [&](int div, bool write) {
+        const float cell = emax / (float)div;
+        int nc[3];
+        for (int k = 0; k < 3; k++) {
+            int m = (int)ceilf(e[k] / cell);
+            nc[k] = m < 1 ? 1 : (m > div ? div : m);
+        }
+        uint32_t found = 0;
+        for (int iz = 0; iz < nc[2]; iz++)
+            for (int iy = 0; iy < nc[1]; iy++)
+                for (int ix = 0; ix < nc[0]; ix++) {
+                    const int idx[3] = {ix, iy, iz};
+                    float clo[3], chi[3], olo[3], ohi[3];
+                    for (int k = 0; k < 3; k++) {
+                        clo[k] = lo[k] + (float)idx[k] * cell;
+                        chi[k] = idx[k] + 1 == nc[k] ? hi[k] : lo[k] + (float)(idx[k] + 1) * cell;
+                    }
+                    if (!clip_bounds(a, b, c, clo, chi, olo, ohi)) continue;
+                    if (write) {
+                        out_tris[w + found] = t;
+                        out_lo[w + found] = make_float4(olo[0], olo[1], olo[2], 0.0f);
+                        out_hi[w + found] = make_float4(ohi[0], ohi[1], ohi[2], 0.0f);
+                    }
+                    found++;
+                }
+        return found;
+    };
+    // an eighth of the longest side; a quarter if that gives too many pieces; else the triangle stays whole.  The write
+    // pass repeats the count pass's decision before it writes anything, so it never touches a neighbour's slots.
+    for (int div = 8; div >= 4; div >>= 1) {
+        const uint32_t found = cells(div, false);
+        if (found == 0) break;                                     // rounding left nothing: keep the triangle whole
+        if (found <= PT_SPLIT_MAX) {
+            if (WRITE) cells(div, true);
+            else counts[g] = found;
+            return;
+        }
+    }
+    whole();
 }
 
 __device__ __forceinline__ unsigned long long spread21(uint32_t v)
@@ -641,6 +762,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     pt_accel_stats& stats = ctx->accel_stats;
     stats = pt_accel_stats{};
     stats.num_triangles = n;
+    ctx->num_refs = 0;
     if (n == 0) { ctx->accel_built = true; return PT_OK; }
     if (n > 0x0FFFFFFFu) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^28-1 triangles");
 
@@ -650,8 +772,8 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     hipEvent_t e0 = ev.a, e1 = ev.b;
     PT_HIP(ctx, hipEventRecord(e0, st));
 
-    DevBuf<TriRec> tris_tmp;
-    DevBuf<float4> tlo, thi, b2lo, b2hi;
+    DevBuf<TriRec> tris_tmp, tris_ref;
+    DevBuf<float4> tlo, thi, rlo, rhi, b2lo, b2hi;
     DevBuf<int> bounds;
     DevBuf<unsigned long long> keys, keys_sorted;
     DevBuf<uint32_t> vals, vals_sorted, parent, flagsb, counters;
@@ -659,12 +781,52 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     DevBuf<CollapseItem> fr[2];
     DevBuf<char> sort_tmp;
     DevBuf<float> cost;
+    const int B = 256;
     PT_HIP(ctx, tris_tmp.alloc(n));
     PT_HIP(ctx, tlo.alloc(n));
     PT_HIP(ctx, thi.alloc(n));
+    PT_HIP(ctx, bounds.alloc(6));
+    k_init_bounds<<<1, 64, 0, st>>>(bounds.p);
+    k_world_tris<false><<<(n + B - 1) / B, B, 0, st>>>(n, ctx->num_submeshes, ctx->d_sub_tri_offset, ctx->d_submeshes, ctx->d_xforms,
+                                                      ctx->d_indices, ctx->d_vertices, tris_tmp.p, tlo.p, thi.p, bounds.p);
+    float lo[3], hi[3], pad;
+    {
+        int rc = scene_extent(ctx, bounds.p, lo, hi, pad);
+        if (rc) return rc;
+    }
+    // from here on n counts references: a split triangle is entered once per piece
+    TriRec* src_tris = tris_tmp.p;
+    float4 *src_lo = tlo.p, *src_hi = thi.p;
+    if (!(flags & PT_BUILD_NO_SPLIT)) {
+        DevBuf<uint32_t> cnt, off;
+        DevBuf<char> scan_tmp;
+        PT_HIP(ctx, cnt.alloc(n));
+        PT_HIP(ctx, off.alloc(n));
+        k_split<false><<<(n + B - 1) / B, B, 0, st>>>(n, tris_tmp.p, tlo.p, thi.p, bounds.p, cnt.p, nullptr, nullptr, nullptr, nullptr);
+        size_t scan_bytes = 0;
+        PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt.p, off.p, (int)n, st));
+        PT_HIP(ctx, scan_tmp.alloc(scan_bytes));
+        PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, cnt.p, off.p, (int)n, st));
+        uint32_t last[2];
+        PT_HIP(ctx, hipMemcpyAsync(&last[0], off.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemcpyAsync(&last[1], cnt.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        const uint64_t nref = (uint64_t)last[0] + last[1];
+        if (nref > 0x0FFFFFFFull) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^28-1 triangle references after splitting");
+        if (nref > n) {
+            PT_HIP(ctx, tris_ref.alloc(nref));
+            PT_HIP(ctx, rlo.alloc(nref));
+            PT_HIP(ctx, rhi.alloc(nref));
+            k_split<true><<<(n + B - 1) / B, B, 0, st>>>(n, tris_tmp.p, tlo.p, thi.p, bounds.p, nullptr, off.p, tris_ref.p, rlo.p, rhi.p);
+            PT_HIP(ctx, hipStreamSynchronize(st));      // cnt / off go out of scope
+            src_tris = tris_ref.p; src_lo = rlo.p; src_hi = rhi.p;
+            n = (uint32_t)nref;
+        }
+    }
+    ctx->num_refs = n;
+    stats.num_references = n;
     PT_HIP(ctx, b2lo.alloc(2 * (size_t)n));
     PT_HIP(ctx, b2hi.alloc(2 * (size_t)n));
-    PT_HIP(ctx, bounds.alloc(6));
     PT_HIP(ctx, keys.alloc(n));
     PT_HIP(ctx, keys_sorted.alloc(n));
     PT_HIP(ctx, vals.alloc(n));
@@ -680,17 +842,8 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_tris, (size_t)n * sizeof(TriRec)));
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_shade_tris, (size_t)n * sizeof(ShadeTri)));
 
-    const int B = 256;
     uint32_t G = (n + B - 1) / B;
-    k_init_bounds<<<1, 64, 0, st>>>(bounds.p);
-    k_world_tris<false><<<G, B, 0, st>>>(n, ctx->num_submeshes, ctx->d_sub_tri_offset, ctx->d_submeshes, ctx->d_xforms,
-                                  ctx->d_indices, ctx->d_vertices, tris_tmp.p, tlo.p, thi.p, bounds.p);
-    float lo[3], hi[3], pad;
-    {
-        int rc = scene_extent(ctx, bounds.p, lo, hi, pad);
-        if (rc) return rc;
-    }
-    k_morton<<<G, B, 0, st>>>(n, tlo.p, thi.p, bounds.p, keys.p, vals.p);
+    k_morton<<<G, B, 0, st>>>(n, src_lo, src_hi, bounds.p, keys.p, vals.p);
     size_t tmp_bytes = 0;
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
     PT_HIP(ctx, sort_tmp.alloc(tmp_bytes));
@@ -700,7 +853,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
         PT_HIP(ctx, hipMemsetAsync(parent.p, 0xFF, 2 * (size_t)n * sizeof(uint32_t), st));
         if (n > 1) k_karras<<<G, B, 0, st>>>((int)n, keys_sorted.p, children.p, parent.p);
-        k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, tlo.p, thi.p, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p);
+        k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, src_lo, src_hi, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p);
     } else {
         DevBuf<uint32_t> cid[2], nearest, totals;
         DevBuf<unsigned long long> pflags, pscan;
@@ -714,7 +867,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         size_t scan_bytes = 0;
         PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, pflags.p, pscan.p, (int)n, st));
         PT_HIP(ctx, scan_tmp.alloc(scan_bytes));
-        k_ploc_init<<<G, B, 0, st>>>((int)n, vals_sorted.p, tlo.p, thi.p, cid[0].p, b2lo.p, b2hi.p);
+        k_ploc_init<<<G, B, 0, st>>>((int)n, vals_sorted.p, src_lo, src_hi, cid[0].p, b2lo.p, b2hi.p);
         uint32_t nc = n, next_id = 0;
         int cur = 0, rounds = 0;
         while (nc > 1) {
@@ -749,7 +902,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         ctx->level_start.push_back(ctx->level_start.back() + nitems);
         PT_HIP(ctx, hipMemsetAsync(counters.p + 2 + (cur ^ 1), 0, sizeof(uint32_t), st));
         k_collapse<<<(nitems + 63) / 64, 64, 0, st>>>(nitems, fr[cur].p, fr[cur ^ 1].p, counters.p + 2 + (cur ^ 1), counters.p, counters.p + 1,
-                                                     (int)n, children.p, b2lo.p, b2hi.p, vals_sorted.p, tris_tmp.p, ctx->d_tris, ctx->d_nodes, pad);
+                                                     (int)n, children.p, b2lo.p, b2hi.p, vals_sorted.p, src_tris, ctx->d_tris, ctx->d_nodes, pad);
         PT_HIP(ctx, hipMemcpyAsync(&nitems, counters.p + 2 + (cur ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipStreamSynchronize(st));
         cur ^= 1;
@@ -789,7 +942,7 @@ int refit_accel(pt_ctx* ctx)
     PT_SYNC(ctx);
     if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "refit: no hierarchy has been built");
     hipStream_t st = ctx->stream;
-    const uint32_t n = ctx->num_tris;
+    const uint32_t n = ctx->num_refs;     // every reference of a split triangle gets the whole triangle's box back: correct, less tight
     pt_accel_stats& stats = ctx->accel_stats;
     if (n == 0) return PT_OK;
     EventPair ev;        // destroyed on every way out

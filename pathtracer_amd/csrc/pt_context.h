@@ -47,6 +47,7 @@ struct pt_ctx {
     uint32_t* d_sub_tri_offset = nullptr;   // num_submeshes + 1
     uint32_t num_vertices = 0, num_indices = 0, num_submeshes = 0, num_materials = 0, num_textures = 0, env_n = 0;
     uint32_t num_tris = 0;
+    uint32_t num_refs = 0;                   // triangle records in leaf order: num_tris, or more when the builder split triangles
     bool scene_loaded = false;
 
     // hierarchy

@@ -594,7 +594,7 @@ SceneView scene_view(const pt_ctx* ctx)
     sv.tex_table = ctx->d_tex_table;
     sv.env = ctx->d_env;
     sv.env_n = ctx->env_n;
-    sv.num_tris = ctx->num_tris;
+    sv.num_tris = ctx->num_refs;
     sv.nodes = ctx->d_nodes;
     sv.tris = ctx->d_tris;
     sv.shade_tris = ctx->d_shade_tris;

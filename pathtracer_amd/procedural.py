@@ -189,25 +189,100 @@ def sponza_materials(full_disney=True):
     return mats
 
 
-def sponza_class(seed=1, full_disney=True, detail=1.0):
-    """~262 k triangles / 103 submeshes / 25 materials at detail = 1."""
+def sponza_textures(size=512, seed=11):
+    """Twelve RGBA8 base-colour textures (bricks, tiles, weave, marble veins, wood grain, plaster ...) and four
+    metallic-roughness maps (G = roughness factor, B = metallic factor, ClosestHit.glsl:182), generated from integer
+    hashes and piecewise-linear waves only, so that every machine produces the same bytes."""
+    n = size
+    y, x = np.mgrid[0:n, 0:n].astype(np.uint32)
+
+    def hash2(a, b, k):
+        h = (a * np.uint32(0x9E3779B1) + b * np.uint32(0x85EBCA77) + np.uint32((k * 0xC2B2AE3D) & 0xFFFFFFFF)).astype(np.uint32)
+        h ^= h >> np.uint32(15)
+        h = (h * np.uint32(0x2C1B3C6D)).astype(np.uint32)
+        h ^= h >> np.uint32(12)
+        return (h & np.uint32(0xFFFF)).astype(np.float32) / np.float32(65535.0)
+
+    def value_noise(cells, k):
+        c = n // cells
+        gx, gy = x // c, y // c
+        fx, fy = (x % c).astype(np.float32) / c, (y % c).astype(np.float32) / c
+        v = lambda ix, iy: hash2(ix % cells, iy % cells, k)   # noqa: E731
+        top = v(gx, gy) * (1 - fx) + v(gx + 1, gy) * fx
+        bot = v(gx, gy + 1) * (1 - fx) + v(gx + 1, gy + 1) * fx
+        return top * (1 - fy) + bot * fy
+
+    def tri(t):                                  # triangle wave in [0, 1], period 1
+        f = t - np.floor(t)
+        return 1 - np.abs(2 * f - 1)
+
+    u, v = x.astype(np.float32) / n, y.astype(np.float32) / n
+    fine = value_noise(64, seed) * 0.6 + value_noise(128, seed + 1) * 0.4
+    coarse = value_noise(8, seed + 2)
+    brick = np.minimum(((v * 8 + 0.02) % 1.0 > 0.08), (((u * 4 + 0.5 * (np.floor(v * 8) % 2)) % 1.0) > 0.04)).astype(np.float32)
+    tiles = (((u * 6) % 1.0 > 0.03) & ((v * 6) % 1.0 > 0.03)).astype(np.float32)
+    weave = 0.5 + 0.5 * tri(u * 48) * tri(v * 48 + 0.25)
+    veins = np.clip(1.0 - 6.0 * np.abs(tri(u * 3 + coarse * 0.7 + v) - 0.5), 0, 1)
+    grain = tri(v * 40 + coarse * 3.0)
+    stripes = (tri(u * 10) > 0.5).astype(np.float32)
+    patterns = [0.55 + 0.45 * brick * (0.8 + 0.2 * fine), 0.5 + 0.5 * tiles * (0.85 + 0.15 * coarse), weave, 1.0 - 0.6 * veins,
+                0.6 + 0.4 * grain, 0.7 + 0.3 * fine, 0.6 + 0.4 * stripes, 0.5 + 0.5 * coarse, 0.75 + 0.25 * tri(u * 24 + fine),
+                0.65 + 0.35 * (fine > 0.5), 0.8 + 0.2 * tri((u + v) * 16), 0.55 + 0.45 * tiles * weave]
+    tints = [(1.0, 0.93, 0.86), (0.95, 0.95, 1.0), (1.0, 0.85, 0.85), (0.97, 0.97, 0.95), (1.0, 0.9, 0.75), (0.96, 0.96, 0.96),
+             (0.9, 0.95, 1.0), (0.9, 1.0, 0.9), (1.0, 0.97, 0.8), (0.93, 0.9, 1.0), (1.0, 0.92, 0.92), (0.92, 1.0, 0.98)]
+    out = []
+    for p_, t_ in zip(patterns, tints):
+        rgb = np.stack([np.clip(p_ * c, 0, 1) for c in t_], axis=-1)
+        out.append(np.concatenate([np.round(rgb * 255).astype(np.uint8), np.full((n, n, 1), 255, np.uint8)], axis=-1))
+    for k in range(4):
+        rough = np.clip(0.55 + 0.45 * (fine if k & 1 else coarse) * (0.7 + 0.3 * tiles), 0, 1)
+        metal = np.clip(0.85 + 0.15 * value_noise(16, seed + 5 + k), 0, 1)
+        mr = np.stack([np.zeros_like(rough), rough, metal, np.ones_like(rough)], axis=-1)
+        out.append(np.round(mr * 255).astype(np.uint8))
+    return out
+
+
+def sponza_class(seed=1, full_disney=True, detail=1.0, layout="uniform", textures=False):
+    """~262 k triangles / 103 submeshes / 25 materials at detail = 1.
+    layout "uniform": every surface finely tessellated (largest triangle 9 % of the scene diagonal).
+    layout "sponza": the size distribution of an architectural model like the real Sponza: floor, walls, gallery slabs and
+    roof as a few large quads (triangles up to a third of the scene), long thin trims and rails (aspect up to 300 : 1) next to
+    the finely tessellated columns, cloth, vases and plants.
+    textures: base-colour maps on every material but the lamps, metallic-roughness maps on a third (Sponza has 69 textures)."""
     rng = np.random.default_rng(seed)
     b = _Builder(0.008)
-    d = lambda n: max(2, int(round(n * math.sqrt(detail))))   # noqa: E731  tessellation per axis
+    arch = layout == "sponza"
+    assert layout in ("uniform", "sponza")
+    boost = 1.04 if arch else 1.0                  # the fine parts take over the triangles the large surfaces give up
+    d = lambda n: max(2, int(round(n * math.sqrt(detail) * boost)))   # noqa: E731  tessellation per axis
+    coarse = lambda n, few: few if arch else d(n) if boost == 1.0 else max(2, int(round(n * math.sqrt(detail))))   # noqa: E731
     X, Z, H1, H2 = 15.0, 9.0, 5.5, 11.0            # half length, half width, storey heights
     nave = 4.2                                       # half width of the open nave
     # shell: floor, four walls (two storeys each), gallery floors, roof strips around the open nave
-    b.merge_add("floor", [_grid((-X, 0, -Z), (0, 0, 2 * Z), (2 * X, 0, 0), d(40), d(64),
-                                disp=lambda s, t: 0.01 * np.sin(40 * s) * np.sin(60 * t))], 0)
+    b.merge_add("floor", [_grid((-X, 0, -Z), (0, 0, 2 * Z), (2 * X, 0, 0), coarse(40, 4), coarse(64, 6),
+                                disp=None if arch else (lambda s, t: 0.01 * np.sin(40 * s) * np.sin(60 * t)))], 0)
     walls = [((-X, 0, -Z), (2 * X, 0, 0), (0, H2 + 1, 0)), ((X, 0, Z), (-2 * X, 0, 0), (0, H2 + 1, 0)),
              ((-X, 0, Z), (0, 0, -2 * Z), (0, H2 + 1, 0)), ((X, 0, -Z), (0, 0, 2 * Z), (0, H2 + 1, 0))]
     for k, (o, du, dv) in enumerate(walls):
-        b.merge_add("wall%d" % k, [_grid(o, du, dv, d(48), d(24), disp=lambda s, t: 0.03 * np.sin(24 * math.pi * s) * np.sin(12 * math.pi * t))], 1 + (k & 1))
+        parts = [_grid(o, du, dv, coarse(48, 3), coarse(24, 2), disp=None if arch else (lambda s, t: 0.03 * np.sin(24 * math.pi * s) * np.sin(12 * math.pi * t)))]
+        if arch:
+            # cornices and skirtings: boxes as long as the wall, a hand wide
+            o_, du_ = np.asarray(o, float), np.asarray(du, float)
+            inward = np.cross(du_ / np.linalg.norm(du_), (0, 1, 0))
+            for y in (0.0, 1.1, H1 - 0.6, H1 + 0.1, H2 - 0.4, H2 + 0.7):
+                p0 = o_ + inward * 0.0 + np.array([0, y, 0])
+                p1 = o_ + du_ + inward * 0.12 + np.array([0, y + 0.1, 0])
+                parts += _box(np.minimum(p0, p1), np.maximum(p0, p1), 1)
+        b.merge_add("wall%d" % k, parts, 1 + (k & 1))
     for k, z0 in enumerate((-Z, nave)):
-        b.merge_add("gallery%d" % k, _box((-X, H1 - 0.25, z0), (X, H1, z0 + (Z - nave)), d(10)), 3)
-        b.merge_add("roof%d" % k, _box((-X, H2, z0), (X, H2 + 0.3, z0 + (Z - nave)), d(10)), 3)
-    for k, x0 in enumerate((-X, X - 3.0)):
-        b.merge_add("roof_end%d" % k, _box((x0, H2, -nave), (x0 + 3.0, H2 + 0.3, nave), d(6)), 3)
+        b.merge_add("gallery%d" % k, _box((-X, H1 - 0.25, z0), (X, H1, z0 + (Z - nave)), coarse(10, 1)), 3)
+        b.merge_add("roof%d" % k, _box((-X, H2, z0), (X, H2 + 0.3, z0 + (Z - nave)), coarse(10, 1)), 3)
+    ends = [_box((x0, H2, -nave), (x0 + 3.0, H2 + 0.3, nave), coarse(6, 1)) for x0 in (-X, X - 3.0)]
+    if arch:
+        b.merge_add("roof_ends", ends[0] + ends[1], 3)     # one submesh, so that the beams below keep the count at 103
+    else:
+        for k in range(2):
+            b.merge_add("roof_end%d" % k, ends[k], 3)
     # columns: 2 rows x 11 x 2 storeys, each its own submesh
     xs = np.linspace(-X + 2.0, X - 2.0, 11)
     ci = 0
@@ -265,7 +340,7 @@ def sponza_class(seed=1, full_disney=True, detail=1.0):
         b.merge_add("orb%d" % k, [_sphere((x, 0.6 + 0.25 * (k % 3), 0.0 + 1.5 * (-1) ** k), 0.6, d(32), d(64))], 20 + k % 4)
     for k in range(4):
         x = -9.0 + 6.0 * k
-        b.merge_add("bench%d" % k, _box((x, 0.0, -0.35), (x + 2.2, 0.5, 0.35), d(6)), 5)
+        b.merge_add("bench%d" % k, _box((x, 0.0, -0.35), (x + 2.2, 0.5, 0.35), coarse(6, 1)), 5)
     # lamps: small emissive spheres under the galleries
     for k, z in enumerate((-Z + 2.0, Z - 2.0)):
         parts = [_sphere((x, H1 - 0.9, z), 0.22, d(10), d(16)) for x in xs[::2]]
@@ -275,9 +350,45 @@ def sponza_class(seed=1, full_disney=True, detail=1.0):
         parts = []
         for x in np.linspace(-X + 2.2, X - 2.2, int(60 * detail) + 2):
             parts.append(_revolve([(0.05, H1), (0.09, H1 + 0.3), (0.05, H1 + 0.6), (0.08, H1 + 0.9)], (x, 0, z), 8))
-        parts += _box((-X + 2.0, H1 + 0.9, z - 0.1), (X - 2.0, H1 + 1.0, z + 0.1), d(8))
+        parts += _box((-X + 2.0, H1 + 0.9, z - 0.1), (X - 2.0, H1 + 1.0, z + 0.1), coarse(8, 1))
         b.merge_add("balustrade%d" % k, parts, 3)
-    sc = b.scene(sponza_materials(full_disney))
+    if arch:
+        # what hurts a hierarchy most: long thin parts that run diagonally through the volume, so that their boxes are
+        # almost empty.  Tie beams from the gallery on one side to the roof edge on the other, skewed along the nave, and
+        # tilted louvre slats over the open nave (sky still shows between them).
+        def oriented_box(p0, p1, half_w, half_h):
+            p0, p1 = np.asarray(p0, float), np.asarray(p1, float)
+            ax = p1 - p0
+            side = np.cross(ax, (0, 1, 0)); side /= np.linalg.norm(side)
+            up = np.cross(side, ax); up /= np.linalg.norm(up)
+            parts = []
+            for sgn_s, sgn_u, (du_, dv_) in ((0, -1, (side * 2 * half_w, ax)), (0, 1, (ax, side * 2 * half_w)),
+                                             (-1, 0, (ax, up * 2 * half_h)), (1, 0, (up * 2 * half_h, ax))):
+                o = p0 - side * half_w - up * half_h
+                if sgn_u > 0:
+                    o = o + up * 2 * half_h
+                if sgn_s > 0:
+                    o = o + side * 2 * half_w
+                parts.append(_grid(o, du_, dv_, 1, 1))
+            return parts
+        beams = []
+        for k, x in enumerate(np.linspace(-X + 3.0, X - 7.0, 12)):
+            z0, z1 = (-nave, nave) if k % 2 == 0 else (nave, -nave)
+            beams += oriented_box((x, H1 + 0.8, z0), (x + 4.0, H2 - 0.4, z1), 0.09, 0.12)
+        slats = []
+        for x in np.linspace(-X + 2.0, X - 4.5, 9):
+            slats.append(_grid((x, H2 + 0.2, -nave - 0.3), (1.9, 1.3, 0.0), (0.0, 0.0, 2 * nave + 0.6), 1, 1))
+        b.merge_add("beams_and_louvres", beams + slats, 7)
+    mats = sponza_materials(full_disney)
+    sc = b.scene(mats)
+    if textures:
+        sc.textures = sponza_textures()
+        sc.texture_flags = [0] * len(sc.textures)
+        ints = sc.materials.view(np.int32)
+        for k in range(24):                      # not the lamps
+            ints[k, 10] = k % 12                  # base colour
+            if k % 3 == 1:
+                ints[k, 11] = 12 + (k // 3) % 4   # metallic-roughness
     return sc
 
 

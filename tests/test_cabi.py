@@ -35,7 +35,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(Params) == 28
     assert C.sizeof(TextureDesc) == 24
     assert C.sizeof(SceneDesc) == 8 * 8 + 6 * 4
-    assert C.sizeof(backend.AccelStats) == 24
+    assert C.sizeof(backend.AccelStats) == 28
     assert C.sizeof(backend.TraceTiming) == 56
 
 

@@ -204,12 +204,20 @@ def decode_child_boxes(node_words):
     return lo, hi, node_words[4:12]
 
 
-def test_hierarchy_is_well_formed(backend, cornell):
+@pytest.mark.parametrize("flags", [2, 0])
+def test_hierarchy_is_well_formed(backend, cornell, flags):
+    """flags 2: every triangle entered once.  flags 0: triangles with mostly empty boxes are entered once per cell they
+    pass through; such a reference's boxes bound its piece only, so containment is checked for the whole triangles."""
     backend.scene_upload(cornell)
-    st = backend.build_accel()
+    st = backend.build_accel(flags)
     nodes, tris = backend.debug_read_bvh()
-    assert nodes.shape == (st.num_nodes, 32)
-    seen = np.zeros(st.num_triangles, bool)
+    assert nodes.shape == (st.num_nodes, 32) and tris.shape == (st.num_references, 12)
+    assert st.num_references >= st.num_triangles and (flags == 0 or st.num_references == st.num_triangles)
+    ids = tris[:, 3].astype(np.uint64) << np.uint64(32) | tris[:, 7].astype(np.uint64)
+    uniq, inverse, counts = np.unique(ids, return_inverse=True, return_counts=True)
+    assert len(uniq) == st.num_triangles         # every (submesh, prim) appears, once unless it was split
+    whole = counts[inverse] == 1
+    seen = np.zeros(st.num_references, bool)
     visited = np.zeros(st.num_nodes, bool)
     tv = tris.view(np.float32).reshape(-1, 3, 4)[:, :, :3].astype(np.float64)
     leaves = 0
@@ -230,15 +238,12 @@ def test_hierarchy_is_well_formed(backend, cornell):
                 assert cnt <= 4 and not seen[first:first + cnt].any()
                 seen[first:first + cnt] = True
                 leaves += 1
-                p = tv[first:first + cnt].reshape(-1, 3)
+                p = tv[first:first + cnt][whole[first:first + cnt]].reshape(-1, 3)
                 for (blo, bhi) in mine:               # every ancestor's decoded box contains the triangles
                     assert (p >= blo).all() and (p <= bhi).all()
             else:
                 stack.append((ch, mine))
     assert seen.all() and visited.all() and leaves == st.num_leaves
-    # every (submesh, prim) appears exactly once
-    ids = tris[:, 3].astype(np.uint64) << np.uint64(32) | tris[:, 7].astype(np.uint64)
-    assert len(np.unique(ids)) == st.num_triangles
 
 
 @pytest.mark.parametrize("flags", [0, 1])
@@ -425,6 +430,81 @@ def test_large_scene(backend):
     o, rays = render_pair(backend, sc, procedural.bistro_camera(W, H), W, H, (1, 2, 3), spp_per_frame=1, max_bounces=8)
     assert backend.accel.num_triangles > 2_900_000 and backend.accel.max_depth >= 10
     assert_same_frame(backend, o, rays)
+
+
+def _world_triangles(sc):
+    """(T, 3, 3) float64 world-space corners of every triangle, in (submesh, prim) order."""
+    out = []
+    for (first_index, first_vertex, _, _), count, xf in zip(sc.submeshes, sc.index_counts, sc.xforms):
+        idx = sc.indices[int(first_index):int(first_index) + int(count)].astype(np.int64) + int(first_vertex)
+        m = np.asarray(xf, np.float64).reshape(3, 4)
+        p = sc.vertices[idx, 0:3].astype(np.float64) @ m[:, :3].T + m[:, 3]
+        out.append(p.reshape(-1, 3, 3))
+    return np.concatenate(out)
+
+
+def test_split_triangles_change_no_result(backend):
+    """Architectural geometry: wall / floor quads spanning the scene and long thin diagonal beams.  The builder enters
+    such triangles once per cell they pass through.  Hits must not change: rays aimed at points spread over the split
+    triangles (and random rays) equal the oracle's brute-force loop and the hierarchy built without splitting, word for
+    word; every reference still names an original (submesh, prim)."""
+    sc = procedural.sponza_class(detail=0.05, layout="sponza", textures=True)
+    backend.scene_upload(sc)
+    whole = backend.build_accel(2)
+    assert whole.num_references == whole.num_triangles == sc.num_triangles
+    rng = np.random.default_rng(77)
+    tri = _world_triangles(sc)
+    e = tri.max(1) - tri.min(1)
+    box_area = 2 * (e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0])
+    big = np.argsort(-box_area)[:400]
+    pick = rng.choice(big, 6000)
+    w = rng.dirichlet((1, 1, 1), len(pick))
+    target = (tri[pick] * w[:, :, None]).sum(1)
+    origin = rng.uniform([-14, 0.3, -8], [14, 10.5, 8], (len(pick), 3))
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aimed = np.zeros((len(pick), 8), np.float32)
+    aimed[:, 0:3], aimed[:, 3], aimed[:, 4:7], aimed[:, 7] = origin, 1e-4, d, 1e27
+    rays = np.concatenate([aimed, random_rays(rng, 6000, [-14, 0.3, -8], [14, 10.5, 8])])
+    h_whole, _ = backend.debug_intersect(rays)
+    st = backend.build_accel(0)
+    assert st.num_triangles == sc.num_triangles and st.num_references > st.num_triangles
+    assert st.sah_cost < whole.sah_cost
+    h_split, _ = backend.debug_intersect(rays)
+    assert np.array_equal(h_split, h_whole)
+    o = oracle_lib.Oracle(sc)
+    assert np.array_equal(h_split, o.intersect(rays, use_bvh=False))
+    assert (h_split[:len(pick), 3] != M32).mean() > 0.95
+    nodes, tris = backend.debug_read_bvh()
+    assert tris.shape == (st.num_references, 12)
+    ids = tris[:, 3].astype(np.uint64) << np.uint64(32) | tris[:, 7].astype(np.uint64)
+    uniq, counts = np.unique(ids, return_counts=True)
+    assert len(uniq) == st.num_triangles and counts.max() <= 64 and (counts > 1).sum() > 50
+    # all references of a triangle carry the same record
+    order = np.argsort(ids, kind="stable")
+    same = ids[order][1:] == ids[order][:-1]
+    assert np.array_equal(tris[order][1:][same], tris[order][:-1][same])
+
+
+def test_split_triangles_frames_bit_exact(backend):
+    """Frames of the architectural scene (textures on every material, split triangles) equal the oracle's, with the
+    split hierarchy, after a refit of it, and without splitting."""
+    sc = procedural.sponza_class(detail=0.05, layout="sponza", textures=True)
+    W, H = 160, 90
+    cam = procedural.sponza_camera(W, H)
+    o, rays = render_pair(backend, sc, cam, W, H, (1, 2, 3), spp_per_frame=1, max_bounces=8)
+    assert backend.accel.num_references > backend.accel.num_triangles
+    assert_same_frame(backend, o, rays)
+    ref = backend.read_accum()
+    backend.update_transforms(sc.xforms, flags=0x100)
+    r0 = backend.ray_count()
+    for f in (1, 2, 3):
+        backend.trace(f)
+    assert backend.ray_count() - r0 == rays and np.array_equal(bits(backend.read_accum()), bits(ref))
+    backend.build_accel(2)
+    for f in (1, 2, 3):
+        backend.trace(f)
+    assert np.array_equal(bits(backend.read_accum()), bits(ref))
 
 
 def test_textured_reference_asset_at_1080p_64_frames(backend):
@@ -807,7 +887,7 @@ def test_transform_edit_with_refit(backend, cornell, cameras):
     import copy
     W, H = 160, 120
     backend.scene_upload(cornell)
-    st0 = backend.build_accel()
+    st0 = backend.build_accel(2)      # no splitting: a refit bounds every reference of a split triangle by the whole triangle
     nodes0, tris0 = backend.debug_read_bvh()
     st = backend.update_transforms(cornell.xforms, UPDATE_REFIT)
     nodes1, tris1 = backend.debug_read_bvh()
