@@ -155,10 +155,12 @@ PT_DEV void trav_init(Trav& s, v3 o, v3 d, float tmin, float tmax)
     if (gabs(cz) < 1e-20f) cz = (f2u(cz) >> 31) ? -1e-20f : 1e-20f;
     s.idx = fdiv(1.0f, cx); s.idy = fdiv(1.0f, cy); s.idz = fdiv(1.0f, cz);
     float oix = o.x * s.idx, oiy = o.y * s.idy, oiz = o.z * s.idz;
-    // rounding of o*idir moves the planes by at most |o*idir| * 2^-24; widen by 4x that
-    float slack = fmaxf(fmaxf(gabs(oix), gabs(oiy)), gabs(oiz)) * 0x1p-22f;
-    s.onx = -oix - slack; s.ony = -oiy - slack; s.onz = -oiz - slack;
-    s.ofx = -oix + slack; s.ofy = -oiy + slack; s.ofz = -oiz + slack;
+    // rounding of o*idir moves an axis' planes by at most |o*idir| * 2^-24 of that axis; widen by 4x that, per axis:
+    // a slack shared by the axes would open the other two slabs of a ray that runs almost parallel to a coordinate
+    // plane (|idir| of one axis huge) so far that no box is culled, and such a ray walks a large part of the hierarchy
+    float slx = gabs(oix) * 0x1p-22f, sly = gabs(oiy) * 0x1p-22f, slz = gabs(oiz) * 0x1p-22f;
+    s.onx = -oix - slx; s.ony = -oiy - sly; s.onz = -oiz - slz;
+    s.ofx = -oix + slx; s.ofy = -oiy + sly; s.ofz = -oiz + slz;
     s.negx = s.idx < 0.0f;
     s.negy = s.idy < 0.0f;
     s.negz = s.idz < 0.0f;

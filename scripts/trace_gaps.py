@@ -29,3 +29,13 @@ for q, ks in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         key = "extend" if "k_extend" in nm else "shade" if "k_shade" in nm else "raygen" if "k_raygen" in nm else "finish" if "k_finish" in nm else "other"
         after[key].append((ks[i + 1][0] - ks[i][1]) * 1e-3)
     print("   mean gap before:", {k: round(sum(v) / len(v), 1) for k, v in after.items()})
+    dur = defaultdict(list)
+    for s_, e_, nm in ks:
+        key = "extend" if "k_extend" in nm else "shade" if "k_shade" in nm else "raygen" if "k_raygen" in nm else "other"
+        dur[key].append((e_ - s_) * 1e-3)
+    print("   mean duration us:", {k: round(sum(v) / len(v), 1) for k, v in dur.items()}, " max extend:", round(max(dur["extend"]) if dur["extend"] else 0, 1))
+
+print("longest kernels:")
+t0 = rows[0][1]
+for name, s_, e_, q in sorted(rows, key=lambda r: r[1] - r[2])[:25]:
+    print("   %8.1f us  queue %s  start %9.1f ms  %s" % ((e_ - s_) * 1e-3, q, (s_ - t0) * 1e-6, name[:60]))

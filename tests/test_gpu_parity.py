@@ -162,6 +162,33 @@ def test_intersect_degenerate_rays(backend, cornell):
     assert tuple(hg[1, 3:5]) == (M32, M32) and tuple(hg[2, 3:5]) == (M32, M32) and tuple(hg[7, 3:5]) == (M32, M32)
 
 
+def test_rays_almost_parallel_to_a_coordinate_plane(backend):
+    """Directions with one component of 1e-5 ... 1e-30 (or zero): 1 / d of that axis is huge.  Hits equal the brute-force
+    loop, and such rays must not cost more than others: the widening of the slab test by the rounding of o / d is per
+    axis, so the huge term of one axis does not open the slabs of the other two."""
+    sc = procedural.sponza_class(detail=0.05)
+    backend.scene_upload(sc)
+    backend.build_accel()
+    rng = np.random.default_rng(5)
+    n = 6000
+    plain = random_rays(rng, n, [-14, 0.3, -8], [14, 10.5, 8])
+    flat = plain.copy()
+    axis = rng.integers(0, 3, n)
+    tiny = (10.0 ** rng.uniform(-30, -5, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    tiny[::7] = 0.0
+    tiny[1::7] = -0.0
+    flat[np.arange(n), 4 + axis] = tiny
+    d = flat[:, 4:7].astype(np.float64)
+    flat[:, 4:7] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    flat[np.arange(n), 4 + axis] = tiny
+    o = oracle_lib.Oracle(sc)
+    h_plain, c_plain = backend.debug_intersect(plain)
+    h_flat, c_flat = backend.debug_intersect(flat)
+    assert np.array_equal(h_flat, o.intersect(flat, use_bvh=False))
+    assert np.array_equal(h_plain, o.intersect(plain, use_bvh=False))
+    assert c_flat[0] < 1.5 * c_plain[0] and c_flat[1] < 1.5 * c_plain[1]
+
+
 def test_tie_rule_and_watertight_edges(backend):
     v = np.zeros((8, 12), np.float32)
     quad = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)]
