@@ -10,13 +10,16 @@ summed with one RCCL reduce inside the timed region.  value = ray segments trace
 max-over-ranks wall time, inputs resident in HBM.
 
 Also reported on the same JSON line:
-  roofline     dominant kernel (k_extend): algorithmic bytes (ray 32 B read + hit 16 B write per ray,
-               128 B per hierarchy node visited, 48 B per triangle tested; counted by the kernel's own
-               counting variant) against the 8 TB/s HBM peak.  A frame runs as `chains` pipelines side by
-               side, so `concurrency` launches of the kernel share the chip at a time: avg_launch_ms is the
-               average duration of one launch (HIP events on the stream it runs on; what rocprofv3 reports),
-               achieved = alg_bytes_per_launch / avg_launch_ms * concurrency = all launches' bytes / the
-               time during which at least one of them was running
+  roofline     what binds the path is vector-instruction issue, not HBM: `bound` "valu", achieved = wave64 vector
+               instructions issued per second by k_extend + k_shade (instructions per ray segment from the committed
+               rocprofv3 --pmc passes, profiles/counters_per_ray.json, times this run's rays per second) against
+               1024 SIMDs x 2.4 GHz / 4 cycles.  The HBM side stays in roofline.hbm: algorithmic bytes of k_extend
+               (ray 32 B read + hit 16 B write per ray, 128 B per hierarchy node visited, 48 B per triangle tested;
+               counted by the kernel's own counting variant) over the time at least one launch was running, and the
+               bytes that crossed the fabric by the counters, both against the 8 TB/s peak.  `traffic` = fabric bytes
+               per k_extend launch.  A frame runs as `chains` pipelines side by side, so `concurrency` launches share
+               the chip at a time: avg_launch_ms is the average duration of one launch (HIP events on the stream it runs
+               on; what rocprofv3 reports).  Workloads without committed counters fall back to the algorithmic HBM figure.
   cpu_baseline the CPU oracle (a port of the reference shaders, not the reference itself) on the
                host cores, rank 0, bounded sample of the same workload
 """
@@ -36,6 +39,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+SIMDS, CLOCK_HZ = 1024, 2.4e9           # 256 CUs x 4 SIMDs, peak engine clock
+VALU_PEAK_GINSTR = SIMDS * CLOCK_HZ / 4.0 / 1e9   # one wave64 vector instruction per SIMD every 4 cycles
 NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 48, 32, 16
 
 
@@ -218,26 +223,67 @@ def main():
         nodes, tris, count_rays = t.nodes_visited, t.tris_tested, t.rays
         b.set_profiling(0)
         alg_bytes = count_rays * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES
-        achieved = alg_bytes / (ext_busy_ms * 1e-3) / 1e9 if ext_busy_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
-        if args.workload == "sponza_class" and os.path.exists(tpath):
+        alg_gbs = alg_bytes / (ext_busy_ms * 1e-3) / 1e9 if ext_busy_ms > 0 else 0.0
+        rays_per_launch = count_rays / max(1, ext_launches)
+        timed_rays_per_s = rays_all / dt_max / max(1, world)          # one GPU's share of the timed region
+        # counters of the two hot kernels per ray segment, from the committed rocprofv3 --pmc passes over this same
+        # workload (profiles/counters_per_ray.json names the commit they were taken at); instructions, busy cycles and
+        # bytes per ray are properties of the code and the scene, the rays and the time are this run's own
+        ctr = None
+        cpath = os.path.join(ROOT, "profiles", "counters_per_ray.json")
+        if args.workload == "sponza_class" and (args.width, args.height, args.bounces, args.detail, args.build_flags) == (1920, 1080, 8, 1.0, 0):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                ctr = json.load(open(cpath))
             except (OSError, ValueError):
-                traffic = None
-        roofline = {
-            "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                ctr = None
+        ce, cs = (ctr or {}).get("k_extend", {}), (ctr or {}).get("k_shade", {})
+        insts_per_ray = (ce.get("valu_insts_per_ray") or 0.0) + (cs.get("valu_insts_per_ray") or 0.0)
+        busy_per_ray = (ce.get("valu_busy_cycles_per_ray") or 0.0) + (cs.get("valu_busy_cycles_per_ray") or 0.0)
+        if insts_per_ray > 0:
+            # what binds the path: vector-instruction issue.  One wave64 instruction holds a SIMD's issue port for 4 cycles
+            # (2 for v_add / v_mul / v_fma / v_mov); peak = 1024 SIMDs x 2.4 GHz / 4
+            achieved = insts_per_ray * timed_rays_per_s / 1e9
+            roofline = {"kernel": "k_extend + k_shade", "bound": "valu", "achieved": round(achieved, 1), "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s",
+                        "frac": round(achieved / VALU_PEAK_GINSTR, 4)}
+        else:
+            roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg_gbs / HBM_PEAK_GBS, 4)}
+        fabric_per_ray = ce.get("fabric_bytes_per_ray")
+        roofline.update({
+            "traffic": int(fabric_per_ray * rays_per_launch) if fabric_per_ray else None,
             "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4), "launches": ext_launches,
             "chains": chains, "concurrency": round(ext_ms / ext_busy_ms, 2) if ext_busy_ms > 0 else None,
             "alg_bytes_per_launch": int(alg_bytes / max(1, ext_launches)),
             "bytes_per_ray": round(alg_bytes / max(1, count_rays), 1),
             "nodes_per_ray": round(nodes / max(1, count_rays), 2), "tris_per_ray": round(tris / max(1, count_rays), 2),
             "profiled_frames": nprof, "frame_ms": {"wall": round(total_ms / nprof, 3), "raygen_sum": round(raygen_ms / nprof, 3),
-                         "extend_busy": round(ext_busy_ms / nprof, 3), "extend_sum": round(ext_ms / nprof, 3),
-                         "shade_sum": round(shade_ms / nprof, 3)},
-        }
+                                                   "extend_busy": round(ext_busy_ms / nprof, 3), "extend_sum": round(ext_ms / nprof, 3),
+                                                   "shade_sum": round(shade_ms / nprof, 3)},
+            # the HBM side of k_extend: algorithmic bytes (every node visit and triangle test counted as memory traffic) over the
+            # time at least one launch was running, and the bytes that crossed the fabric (counters, doubled FETCH_SIZE: an estimate
+            # for per-lane gathers) at this run's ray rate
+            "hbm": {"alg_bandwidth_gbs": round(alg_gbs, 1), "alg_frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                    "fabric_gbs": round(fabric_per_ray * timed_rays_per_s / 1e9, 1) if fabric_per_ray else None,
+                    "fabric_frac": round(fabric_per_ray * timed_rays_per_s / 1e9 / HBM_PEAK_GBS, 4) if fabric_per_ray else None,
+                    "l2_hit_rate": round(ce["l2_hit_rate"], 3) if "l2_hit_rate" in ce else None, "peak_gbs": HBM_PEAK_GBS},
+            "valu": None if insts_per_ray <= 0 else {
+                "extend_insts_per_ray": round(ce.get("valu_insts_per_ray", 0.0), 1), "shade_insts_per_ray": round(cs.get("valu_insts_per_ray", 0.0), 1),
+                "insts_per_launch": int(ce.get("valu_insts_per_ray", 0.0) * rays_per_launch),
+                "issue_slot_frac": round(insts_per_ray * timed_rays_per_s * 4.0 / (SIMDS * CLOCK_HZ), 4),
+                "pipe_busy_frac": round(busy_per_ray * timed_rays_per_s / (SIMDS * CLOCK_HZ), 4) if busy_per_ray else None,
+                "note": "wave64 vector instructions per ray segment x this run's rays per second x 4 cycles / (1024 SIMDs x 2.4 GHz); "
+                        "pipe_busy_frac uses SQ_ACTIVE_INST_VALU instead of 4 cycles per instruction; the clock under this load is below 2.4 GHz",
+                "profile_commit": ctr.get("commit"), "profile": "profiles/counters_per_ray.json"},
+            # second kernel: sky or surface fetch + Disney sample / eval + next ray; algorithmic bytes per ray segment: queue and path
+            # state 168 B, surface <= 308 B on a hit
+            "k_shade": {"avg_launch_ms": round(shade_ms / max(1, ext_launches), 4), "launches": ext_launches,
+                        "alg_bytes_per_ray": {"queue_and_state": 168, "surface_on_hit_max": 308},
+                        "alg_bandwidth_gbs": round((168 + 308) * timed_rays_per_s / 1e9, 1),
+                        "fabric_bytes_per_ray": round(cs["fabric_bytes_per_ray"], 1) if "fabric_bytes_per_ray" in cs else None,
+                        "l2_hit_rate": round(cs["l2_hit_rate"], 3) if "l2_hit_rate" in cs else None,
+                        "parked_share_of_wave_cycles": round(cs["parked_share_of_wave_cycles"], 3) if "parked_share_of_wave_cycles" in cs else None,
+                        "valu_insts_per_ray": round(cs["valu_insts_per_ray"], 1) if "valu_insts_per_ray" in cs else None},
+        })
 
         # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload ----
         cpu = None

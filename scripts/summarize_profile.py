@@ -1,8 +1,10 @@
 """Turns the rocprofv3 databases written by scripts/profile.sh into the summaries kept under profiles/.
 
-usage: python scripts/summarize_profile.py gpurun_out/prof_r01 r01
-writes profiles/<tag>_kernel_stats.md, profiles/<tag>_pmc.json and profiles/extend_traffic.json
-(the HBM bytes per k_extend launch that bench.py reports as roofline.traffic).
+usage: python scripts/summarize_profile.py gpurun_out/prof_r01 r01 [commit]
+writes profiles/<tag>_kernel_stats.md, profiles/<tag>_pmc.json, profiles/extend_traffic.json
+(the HBM bytes per k_extend launch that bench.py reports as roofline.traffic) and
+profiles/counters_per_ray.json: vector instructions, vector-pipe busy cycles, fabric bytes, L2 hit rate and
+parked share of k_extend and k_shade per ray segment, which bench.py scales by the rays of its own run.
 """
 import glob
 import json
@@ -93,6 +95,45 @@ if "FETCH_SIZE" in ext:
 if "TCC_HIT_sum" in ext and "TCC_MISS_sum" in ext:
     h, m = ext["TCC_HIT_sum"]["sum"], ext["TCC_MISS_sum"]["sum"]
     summary["extend_l2_hit_rate"] = h / (h + m) if h + m else None
+
+# ---- per ray segment: counter sums of the production kernels over the rays those launches traced ----
+# every pass runs the same bench.py command: frame 1, the warm-up, the timed frames and 16 event-timed frames run the plain
+# traversal kernels (k_extend<false, *>), then 16 counted frames run k_extend<true, *>; k_shade serves all of them
+try:
+    bench = [json.loads(l) for l in open(os.path.join(src, "trace.log")) if l.startswith('{"metric"')][-1]
+    rays_per_frame = bench["config"]["rays_per_step_per_gpu"]
+    plain_frames = 1 + bench["warmup"] + bench["steps"] + bench["roofline"]["profiled_frames"]
+    all_frames = plain_frames + bench["roofline"]["profiled_frames"]
+
+    def per_ray(kernels, frames):
+        out = {}
+        tot = {}
+        for k in kernels:
+            for c, v in pmc.get(k, {}).items():
+                tot[c] = tot.get(c, 0.0) + v["sum"]
+        rays = float(rays_per_frame) * frames
+        if "SQ_INSTS_VALU" in tot:
+            out["valu_insts_per_ray"] = tot["SQ_INSTS_VALU"] / rays
+        if "SQ_ACTIVE_INST_VALU" in tot:
+            out["valu_busy_cycles_per_ray"] = 4.0 * tot["SQ_ACTIVE_INST_VALU"] / rays     # the counter ticks every four cycles
+        if "FETCH_SIZE" in tot:
+            out["fabric_bytes_per_ray"] = (2.0 * tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / rays
+        if "TCC_HIT_sum" in tot and tot["TCC_HIT_sum"] + tot.get("TCC_MISS_sum", 0.0) > 0:
+            out["l2_hit_rate"] = tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"])
+        if "SQ_WAIT_ANY" in tot and tot.get("SQ_WAVE_CYCLES"):
+            out["parked_share_of_wave_cycles"] = tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"]
+        return out
+
+    per = {"source": "rocprofv3 --pmc passes of scripts/profile.sh (FETCH_SIZE doubled per the gfx950 rule for 16-byte-per-lane reads: an "
+                     "estimate for per-lane node gathers), summed over all launches of the kernel and divided by the ray segments they traced",
+           "commit": sys.argv[3] if len(sys.argv) > 3 else None, "tag": tag,
+           "workload": bench["config"]["workload"], "rays_per_frame": rays_per_frame,
+           "k_extend": per_ray(["ptd::k_extend<false, true>", "ptd::k_extend<false, false>"], plain_frames),
+           "k_shade": per_ray(["ptd::k_shade"], all_frames)}
+    summary["per_ray"] = per
+    json.dump(per, open(os.path.join(out_dir, "counters_per_ray.json"), "w"), indent=1)
+except (OSError, IndexError, KeyError, ValueError) as e:
+    print("no per-ray summary:", e)
 json.dump(summary, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
 print("\n".join(lines[:14]))
 print(json.dumps({k: v for k, v in summary.items() if k != "per_kernel"}, indent=1))
