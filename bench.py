@@ -230,8 +230,8 @@ def main():
         # workload (profiles/counters_per_ray.json names the commit they were taken at); instructions, busy cycles and
         # bytes per ray are properties of the code and the scene, the rays and the time are this run's own
         ctr = None
-        cpath = os.path.join(ROOT, "profiles", "counters_per_ray.json")
-        if args.workload == "sponza_class" and (args.width, args.height, args.bounces, args.detail, args.build_flags) == (1920, 1080, 8, 1.0, 0):
+        cpath = os.path.join(ROOT, "profiles", "counters_per_ray.json" if args.workload == "sponza_class" else "counters_per_ray_%s.json" % args.workload)
+        if (args.width, args.height, args.bounces, args.detail, args.build_flags) == (1920, 1080, 8, 1.0, 0):
             try:
                 ctr = json.load(open(cpath))
             except (OSError, ValueError):
@@ -273,7 +273,7 @@ def main():
                 "pipe_busy_frac": round(busy_per_ray * timed_rays_per_s / (SIMDS * CLOCK_HZ), 4) if busy_per_ray else None,
                 "note": "wave64 vector instructions per ray segment x this run's rays per second x 4 cycles / (1024 SIMDs x 2.4 GHz); "
                         "pipe_busy_frac uses SQ_ACTIVE_INST_VALU instead of 4 cycles per instruction; the clock under this load is below 2.4 GHz",
-                "profile_commit": ctr.get("commit"), "profile": "profiles/counters_per_ray.json"},
+                "profile_commit": ctr.get("commit"), "profile": "profiles/" + os.path.basename(cpath)},
             # second kernel: sky or surface fetch + Disney sample / eval + next ray; algorithmic bytes per ray segment: queue and path
             # state 168 B, surface <= 308 B on a hit
             "k_shade": {"avg_launch_ms": round(shade_ms / max(1, ext_launches), 4), "launches": ext_launches,

@@ -3,7 +3,8 @@
 usage: python scripts/summarize_profile.py gpurun_out/prof_r01 r01 [commit]
 writes profiles/<tag>_kernel_stats.md, profiles/<tag>_pmc.json, profiles/extend_traffic.json
 (the HBM bytes per k_extend launch that bench.py reports as roofline.traffic) and
-profiles/counters_per_ray.json: vector instructions, vector-pipe busy cycles, fabric bytes, L2 hit rate and
+profiles/counters_per_ray.json (counters_per_ray_<workload>.json for another workload: BENCH_ARGS="--workload ..." to
+profile.sh and a tag like r02_bistro): vector instructions, vector-pipe busy cycles, fabric bytes, L2 hit rate and
 parked share of k_extend and k_shade per ray segment, which bench.py scales by the rays of its own run.
 """
 import glob
@@ -91,7 +92,8 @@ if "FETCH_SIZE" in ext:
                "note": "FETCH_SIZE doubled per the gfx950 correction for 16-byte-per-lane reads; WRITE_SIZE as reported; "
                        "Infinity-Cache hits are included in these fabric-side counters"}
     summary["extend_traffic"] = traffic
-    json.dump(traffic, open(os.path.join(out_dir, "extend_traffic.json"), "w"), indent=1)
+    if tag.count("_") == 0:      # the benchmark workload's own profile
+        json.dump(traffic, open(os.path.join(out_dir, "extend_traffic.json"), "w"), indent=1)
 if "TCC_HIT_sum" in ext and "TCC_MISS_sum" in ext:
     h, m = ext["TCC_HIT_sum"]["sum"], ext["TCC_MISS_sum"]["sum"]
     summary["extend_l2_hit_rate"] = h / (h + m) if h + m else None
@@ -131,7 +133,8 @@ try:
            "k_extend": per_ray(["ptd::k_extend<false, true>", "ptd::k_extend<false, false>"], plain_frames),
            "k_shade": per_ray(["ptd::k_shade"], all_frames)}
     summary["per_ray"] = per
-    json.dump(per, open(os.path.join(out_dir, "counters_per_ray.json"), "w"), indent=1)
+    wl = bench["config"]["workload"].split(",")[0]
+    json.dump(per, open(os.path.join(out_dir, "counters_per_ray.json" if wl == "sponza_class" else "counters_per_ray_%s.json" % wl), "w"), indent=1)
 except (OSError, IndexError, KeyError, ValueError) as e:
     print("no per-ray summary:", e)
 json.dump(summary, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
