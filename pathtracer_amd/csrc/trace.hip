@@ -668,13 +668,18 @@ int launch_trace(pt_ctx* ctx)
         return per_shard * spc;
     };
     // traversal waves per CU over all chains: enough for every chain's launch to fill its share of the chip, few enough
-    // for a wave to refill its lanes several times (measured optimum 40 for 8 chains, 48 for 16)
+    // for a wave to refill its lanes several times (measured: 40 for 8 chains; for 16 chains flat from 96 to 128, 48 is 3-4 %
+    // slower on a mid-sized and on a large scene, 192 loses 5 % on the mid-sized one)
     static const uint32_t waves_override = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 0u;
-    const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? 48u : 40u);
+    // a shallow scene (surface-area cost below 20: a ray is done after two or three node steps, so a wave mostly refills)
+    // prefers half as many: the Cornell box loses 11 % at 96
+    const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? (ctx->accel_stats.sah_cost >= 20.0f ? 96u : 48u) : 40u);
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
     static const uint32_t shade_override = getenv("PT_SHADE_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("PT_SHADE_BLOCKS_PER_CU")) : 0u;
-    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, (uint32_t)ctx->num_cus * (shade_override ? shade_override : 8u), nframes);
+    // shading: 4 workgroups of 256 per CU over all chains (measured: 8 is 1.5-3.5 % slower on four scenes, 2 is 1-5 % slower):
+    // the launch waits on gathers, and waves it holds beyond that only take registers from the traversal
+    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, (uint32_t)ctx->num_cus * (shade_override ? shade_override : 4u), nframes);
     // a chain's share of the spill area and of the suspension records is laid out for a full batch, so that a
     // short batch launched while a full one is still running stays inside its own chain's share
     const uint32_t ext_blocks_max = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, PT_MAX_BATCH);
