@@ -447,7 +447,14 @@ __global__ void __launch_bounds__(256) k_accumulate(TraceParams P, Queues q)
     }
 }
 
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
+// Shading is compiled for 96 registers (5 waves per SIMD): a traversal wave takes 104 of a SIMD's 512 and four of them
+// leave 96, so a shading wave of this size runs beside four traversal waves where the unconstrained kernel (140 registers)
+// displaced one of them.  The price is 43 spilled words per lane; measured +1 ... +4.5 % of the frame on four scenes, while a
+// limit of 128 registers (room beside three traversal waves only, like 140) measured -1 ... -3 %.
+#ifndef PT_SHADE_WAVES_PER_SIMD
+#define PT_SHADE_WAVES_PER_SIMD 5
+#endif
+__global__ void __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES_PER_SIMD, PT_SHADE_WAVES_PER_SIMD))) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
 {
     const uint32_t ls = blockIdx.x % q.nshards, lb = blockIdx.x / q.nshards, nb = gridDim.x / q.nshards;
     const uint32_t shard = q.shard0 + ls;
