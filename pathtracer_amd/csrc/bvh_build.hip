@@ -14,12 +14,16 @@
 //         one cluster is left (k_ploc_nearest, k_ploc_flags, scan, k_ploc_merge).  Near-SAH quality.
 //      b. PT_BUILD_LBVH: binary radix tree over the sorted codes (Karras 2012, k_karras) and bottom-up
 //         boxes with an arrival counter per node (k_refit).  Fastest build, about 1.6x the traversal cost.
-//   5. k_collapse     level by level: binary tree -> 8-wide nodes of 128 bytes with 8-bit quantised child
-//                     boxes, subtrees of <= 4 triangles become leaves, triangles are written out in leaf order
+//   5. k_collapse_dp  which subtrees become the children of an 8-wide node: surface-area-optimal, by a dynamic programme
+//                     over the binary tree (clustered trees; PT_BUILD_GREEDY or PT_BUILD_LBVH: open the largest box first)
+//      k_collapse     level by level: binary tree -> 8-wide nodes of 128 bytes with 8-bit quantised child
+//                     boxes, leaves of <= 4 triangles, triangles are written out in leaf order
 #include "pt_context.h"
 #include "pt_traverse.h"
 #include "pt_math.h"
 #include <hipcub/hipcub.hpp>
+#include <utility>
+#include <vector>
 
 namespace ptd {
 
@@ -504,11 +508,90 @@ __device__ __forceinline__ void store_child_planes(Node8& nd, int k, const uint3
     }
 }
 
-// one thread per frontier item: builds one Node8 and queues its internal children
+// ---- which subtrees of the binary tree become the children of an 8-wide node ---------------------------------------
+// Surface-area-optimal choice by a dynamic programme over the binary tree (after Ylitie, Karras, Laine: "Efficient
+// incoherent ray traversal on GPUs through compressed wide BVHs", 2017, section 3.2).  c(n, i) = cheapest way to present
+// subtree n to a parent as at most i children:
+//   c(n, 1) = min(leaf(n), node(n))         leaf(n) = A(n) (C_leaf + P(n) C_tri) if n holds at most PT_LEAF_MAX triangles
+//                                            node(n) = A(n) C_node + split(n, 8)
+//   c(n, i) = min(split(n, i), c(n, i - 1))  split(n, j) = min over k of c(left, k) + c(right, j - k)
+// with A the box area relative to the root's.  The cost ratios are measured, not derived: by instruction counts a triangle
+// test is 0.8 of a node step, but throughput on three scenes is flat between C_tri = 0.2 and 0.3 with C_leaf = 0.3 to 0.5 and
+// 1 to 3 % lower at 0.8 (the surface-area model overrates how often a leaf's triangles are reached behind a closer hit).
+// The greedy rule it replaces (open the child with the largest box until eight are open, every subtree of at most four
+// triangles a leaf) left 39 % of all nodes with two children: a subtree of 5 to 8 triangles beside large siblings.
+#ifndef PT_COST_NODE
+#define PT_COST_NODE 1.0f
+#define PT_COST_TRI 0.25f
+#define PT_COST_LEAF 0.4f
+#endif
+// per internal node of the binary tree: c(n, 1..7) and the choices behind them.  choice bits: 3 * (j - 2) + {0, 1, 2} =
+// k of split(n, j), j = 2..8; bit 21 = a leaf is cheaper than a node; bit 22 + (i - 2) = c(n, i) takes c(n, i - 1), i = 2..7
+struct CollapseDp { float c[7]; uint32_t choice; };
+
+__device__ __forceinline__ float dp_area(float4 lo, float4 hi)
+{
+    float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+    if (!(ex >= 0.0f && ey >= 0.0f && ez >= 0.0f)) return 0.0f;      // the empty box of triangles that cannot be hit
+    return ex * ey + ey * ez + ez * ex;
+}
+
+// nodes [first, first + count) of the binary tree, whose children are leaves or have smaller numbers than first
+__global__ void k_collapse_dp(uint32_t first, uint32_t count, int n, uint32_t root, const uint2* __restrict__ children,
+                              const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, CollapseDp* dp)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    const uint32_t id = first + g;
+    float root_area = dp_area(b2lo[root], b2hi[root]);
+    const float inv_root = root_area > 0.0f ? 1.0f / root_area : 1.0f;
+    const uint2 ch = children[id];
+    float cl[8], cr[8];
+    auto load = [&](uint32_t c, float* out) {
+        if (c >= (uint32_t)(n - 1)) {
+            float v = dp_area(b2lo[c], b2hi[c]) * inv_root * (PT_COST_LEAF + PT_COST_TRI);
+            for (int i = 1; i < 8; i++) out[i] = v;
+        } else {
+            for (int i = 1; i < 8; i++) out[i] = dp[c].c[i - 1];
+        }
+    };
+    load(ch.x, cl);
+    load(ch.y, cr);
+    const float4 lo = b2lo[id], hi = b2hi[id];
+    const float A = dp_area(lo, hi) * inv_root;
+    const uint32_t P = __float_as_uint(lo.w);
+    float split[9];
+    uint32_t choice = 0;
+    for (int j = 2; j <= 8; j++) {
+        float best = __builtin_inff();
+        uint32_t bk = 1;
+        for (int k = 1; k < j; k++) {
+            float v = cl[k] + cr[j - k];
+            if (v < best) { best = v; bk = (uint32_t)k; }
+        }
+        split[j] = best;
+        choice |= bk << (3 * (j - 2));
+    }
+    const float c_node = A * PT_COST_NODE + split[8];
+    const float c_leaf = P <= PT_LEAF_MAX ? A * (PT_COST_LEAF + (float)P * PT_COST_TRI) : __builtin_inff();
+    CollapseDp r;
+    r.c[0] = fminf(c_leaf, c_node);
+    if (c_leaf <= c_node) choice |= 1u << 21;
+    for (int i = 2; i <= 7; i++) {
+        if (r.c[i - 2] <= split[i]) { r.c[i - 1] = r.c[i - 2]; choice |= 1u << (22 + i - 2); }
+        else r.c[i - 1] = split[i];
+    }
+    r.choice = choice;
+    dp[id] = r;
+}
+
+// one thread per frontier item: builds one Node8 and queues its internal children.  dp == nullptr: greedy choice of the
+// children (open the one with the largest box), every subtree of at most PT_LEAF_MAX triangles a leaf
 __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in, CollapseItem* __restrict__ out, uint32_t* out_count,
                            uint32_t* node_counter, uint32_t* leaf_counter, int n, const uint2* __restrict__ children,
                            const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, const uint32_t* __restrict__ vals,
-                           const TriRec* __restrict__ tris_in, TriRec* __restrict__ tris_out, Node8* __restrict__ nodes, float pad)
+                           const TriRec* __restrict__ tris_in, TriRec* __restrict__ tris_out, Node8* __restrict__ nodes, float pad,
+                           const CollapseDp* __restrict__ dp)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nitems) return;
@@ -517,9 +600,38 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
     int nc;
     auto count_of = [&](uint32_t id) { return __float_as_uint(b2lo[id].w); };
     auto is_leaf2 = [&](uint32_t id) { return id >= (uint32_t)(n - 1); };
-    if (is_leaf2(it.node2) || count_of(it.node2) <= PT_LEAF_MAX) {
+    // does subtree c, presented as one child, become a leaf?
+    auto leafy = [&](uint32_t c) {
+        if (is_leaf2(c)) return true;
+        if (count_of(c) > PT_LEAF_MAX) return false;
+        return dp ? ((dp[c].choice >> 21) & 1u) != 0 : true;
+    };
+    if (leafy(it.node2)) {
         cand[0] = it.node2;   // only the root can get here: the whole scene fits one leaf
         nc = 1;
+    } else if (dp) {
+        // follow the programme's choices from split(node, 8) down to subtrees that are presented as one child
+        uint32_t st_id[8];
+        int st_j[8], sp = 0;
+        nc = 0;
+        {
+            uint2 ch = children[it.node2];
+            int k = (int)((dp[it.node2].choice >> 18) & 7u);
+            st_id[sp] = ch.y; st_j[sp++] = 8 - k;
+            st_id[sp] = ch.x; st_j[sp++] = k;
+        }
+        while (sp) {
+            uint32_t id = st_id[--sp];
+            int j = st_j[sp];
+            if (is_leaf2(id) || j == 1) { cand[nc++] = id; continue; }
+            uint32_t choice = dp[id].choice;
+            while (j >= 2 && ((choice >> (22 + j - 2)) & 1u)) j--;
+            if (j == 1) { cand[nc++] = id; continue; }
+            int k = (int)((choice >> (3 * (j - 2))) & 7u);
+            uint2 ch = children[id];
+            st_id[sp] = ch.y; st_j[sp++] = j - k;
+            st_id[sp] = ch.x; st_j[sp++] = k;
+        }
     } else {
         uint2 ch = children[it.node2];
         cand[0] = ch.x; cand[1] = ch.y;
@@ -577,7 +689,7 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
             float4 lo = b2lo[c], hi = b2hi[c];
             uint32_t cnt = __float_as_uint(lo.w);
             quantise_child(gr, lo, hi, pad, qlo, qhi);
-            if (cnt <= PT_LEAF_MAX) {
+            if (leafy(c)) {
                 nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
                 // write the subtree's triangles in depth-first order
                 uint32_t stack[16];
@@ -779,6 +891,8 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     DevBuf<uint32_t> vals, vals_sorted, parent, flagsb, counters;
     DevBuf<uint2> children;
     DevBuf<CollapseItem> fr[2];
+    DevBuf<CollapseDp> dp;
+    std::vector<std::pair<uint32_t, uint32_t>> dp_rounds;     // (first node, count) of every clustering round: children before parents
     DevBuf<char> sort_tmp;
     DevBuf<float> cost;
     const int B = 256;
@@ -882,11 +996,17 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
             PT_HIP(ctx, hipStreamSynchronize(st));
             if (ht[1] == 0 || ht[0] != nc - ht[1]) return set_error(ctx, PT_ERR_INVALID, "hierarchy build: clustering made no progress");
             nc = ht[0];
+            dp_rounds.emplace_back(next_id, ht[1]);
             next_id += ht[1];
             cur ^= 1;
             if (++rounds > 4096) return set_error(ctx, PT_ERR_INVALID, "hierarchy build: clustering did not terminate");
         }
         root_id = n > 1 ? next_id - 1 : 0;   // the last node created is the root
+        if (n > 1 && !(flags & PT_BUILD_GREEDY)) {
+            PT_HIP(ctx, dp.alloc(n));
+            for (auto& r : dp_rounds)
+                k_collapse_dp<<<(r.second + B - 1) / B, B, 0, st>>>(r.first, r.second, (int)n, root_id, children.p, b2lo.p, b2hi.p, dp.p);
+        }
     }
 
     // collapse: counters[0] = nodes allocated, [1] = leaves, [2],[3] = frontier sizes (ping-pong)
@@ -902,7 +1022,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         ctx->level_start.push_back(ctx->level_start.back() + nitems);
         PT_HIP(ctx, hipMemsetAsync(counters.p + 2 + (cur ^ 1), 0, sizeof(uint32_t), st));
         k_collapse<<<(nitems + 63) / 64, 64, 0, st>>>(nitems, fr[cur].p, fr[cur ^ 1].p, counters.p + 2 + (cur ^ 1), counters.p, counters.p + 1,
-                                                     (int)n, children.p, b2lo.p, b2hi.p, vals_sorted.p, src_tris, ctx->d_tris, ctx->d_nodes, pad);
+                                                     (int)n, children.p, b2lo.p, b2hi.p, vals_sorted.p, src_tris, ctx->d_tris, ctx->d_nodes, pad, dp.p);
         PT_HIP(ctx, hipMemcpyAsync(&nitems, counters.p + 2 + (cur ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipStreamSynchronize(st));
         cur ^= 1;

@@ -41,7 +41,7 @@ namespace ptd {
 #define PT_REFILL_MIN 20   // free lanes that trigger a refill
 #endif
 #ifndef PT_LEAF_MIN
-#define PT_LEAF_MIN 12     // lanes with a pending leaf that trigger the triangle phase while others still walk nodes
+#define PT_LEAF_MIN 16     // lanes with a pending leaf that trigger the triangle phase while others still walk nodes
 #endif
 #ifndef PT_CUT_LANES
 #define PT_CUT_LANES 16    // a wave whose queue ran dry suspends its rays once no more than this many are in flight
