@@ -675,12 +675,12 @@ int launch_trace(pt_ctx* ctx)
         return per_shard * spc;
     };
     // traversal waves per CU over all chains: enough for every chain's launch to fill its share of the chip, few enough
-    // for a wave to refill its lanes several times (measured: 40 for 8 chains; for 16 chains flat from 96 to 128, 48 is 3-4 %
-    // slower on a mid-sized and on a large scene, 192 loses 5 % on the mid-sized one)
+    // for a wave to refill its lanes several times (measured: 40 for 8 chains; for 16 chains flat from 64 to 96, 48 is 3-4 %
+    // slower on a mid-sized and on a large scene, 128 loses 1-3 %, 192 loses 5 %)
     static const uint32_t waves_override = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 0u;
     // a shallow scene (surface-area cost below 20: a ray is done after two or three node steps, so a wave mostly refills)
-    // prefers half as many: the Cornell box loses 11 % at 96
-    const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? (ctx->accel_stats.sah_cost >= 20.0f ? 96u : 48u) : 40u);
+    // prefers fewer: the Cornell box loses 11 % at 96
+    const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? (ctx->accel_stats.sah_cost >= 20.0f ? 64u : 48u) : 40u);
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
     static const uint32_t shade_override = getenv("PT_SHADE_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("PT_SHADE_BLOCKS_PER_CU")) : 0u;
