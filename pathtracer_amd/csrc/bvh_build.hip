@@ -4,7 +4,7 @@
 //
 // Pipeline (all on the context's stream):
 //   1. k_world_tris   every submesh triangle -> world space (object-to-world 3x4), its box, scene bounds
-//   1b. k_split       long thin triangles whose boxes are mostly empty are entered once per cell they pass through
+//   1b. k_split_*     large triangles whose boxes are mostly empty are entered once per cell they pass through (one wave per such triangle)
 //   2. k_morton       63-bit Morton code of the box centre
 //   3. radix sort     (rocPRIM via hipcub) of (code, triangle)
 //   4. binary hierarchy, one of
@@ -181,72 +181,109 @@ __device__ bool clip_bounds(v3 a, v3 b, v3 c, const float* clo, const float* chi
     return true;
 }
 
-// WRITE = false: counts[g] = references of triangle g.  WRITE = true: writes them at offsets[g].
-template <bool WRITE>
-__global__ void k_split(uint32_t n, const TriRec* __restrict__ tris, const float4* __restrict__ tlo, const float4* __restrict__ thi,
-                        const int* __restrict__ bounds, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                        TriRec* __restrict__ out_tris, float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+// Pass 1, one thread per triangle: mode[g] = 0 for a triangle that stays whole (counts[g] = 1), 0xFF for a candidate, which
+// is also appended to the candidate list.
+__global__ void k_split_classify(uint32_t n, const TriRec* __restrict__ tris, const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                                 const int* __restrict__ bounds, uint32_t* __restrict__ counts, unsigned char* __restrict__ mode,
+                                 uint32_t* __restrict__ cand, uint32_t* ncand)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
+    counts[g] = 1u;
+    mode[g] = 0;
+    const float4 lo = tlo[g], hi = thi[g];
+    if (!(lo.x <= hi.x)) return;                                  // the empty box of a triangle that cannot be hit
     const TriRec t = tris[g];
-    const float4 lo4 = tlo[g], hi4 = thi[g];
-    const float lo[3] = {lo4.x, lo4.y, lo4.z}, hi[3] = {hi4.x, hi4.y, hi4.z};
-    uint32_t w = WRITE ? offsets[g] : 0u;
-    auto whole = [&]() {
-        if (WRITE) { out_tris[w] = t; out_lo[w] = lo4; out_hi[w] = hi4; }
-        else counts[g] = 1u;
-    };
-    if (!(lo[0] <= hi[0])) { whole(); return; }                   // the empty box of a triangle that cannot be hit
-    const float e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    const float e[3] = {hi.x - lo.x, hi.y - lo.y, hi.z - lo.z};
     const float sa = 2.0f * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
     const float sx = ord2f(bounds[3]) - ord2f(bounds[0]), sy = ord2f(bounds[4]) - ord2f(bounds[1]), sz = ord2f(bounds[5]) - ord2f(bounds[2]);
     const float scene_sa = 2.0f * (sx * sy + sy * sz + sz * sx);
     const v3 a = V3(t.v0x, t.v0y, t.v0z), b = V3(t.v1x, t.v1y, t.v1z), c = V3(t.v2x, t.v2y, t.v2z);
     const v3 cr = cross(b - a, c - a);
     const float two_sided = sqrtf(dot(cr, cr));                    // 2 * (|cross| / 2)
-    if (!(sa > scene_sa * (1.0f / PT_SPLIT_AREA_DIV)) || !(sa > PT_SPLIT_WASTE * two_sided)) { whole(); return; }
+    if (!(sa > scene_sa * (1.0f / PT_SPLIT_AREA_DIV)) || !(sa > PT_SPLIT_WASTE * two_sided)) return;
+    mode[g] = 0xFF;
+    cand[atomicAdd(ncand, 1u)] = g;
+}
+
+// One wave per candidate; the lanes share out the cells of the grid over the triangle's box (up to 8 x 8 x 8).
+// WRITE = false: decides the grid (an eighth of the longest side; a quarter if that gives more than PT_SPLIT_MAX pieces;
+// else the triangle stays whole) and leaves it in mode[g] (8, 4 or 0) with the number of pieces in counts[g].
+// WRITE = true: writes the pieces of the grid in mode[g] at offsets[g], in cell order.
+template <bool WRITE>
+__global__ void __launch_bounds__(64) k_split_cells(uint32_t ncand, const uint32_t* __restrict__ cand, const TriRec* __restrict__ tris,
+                                                    const float4* __restrict__ tlo, const float4* __restrict__ thi, uint32_t* __restrict__ counts,
+                                                    unsigned char* __restrict__ mode, const uint32_t* __restrict__ offsets,
+                                                    TriRec* __restrict__ out_tris, float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+{
+    if (blockIdx.x >= ncand) return;
+    const uint32_t g = cand[blockIdx.x], lane = threadIdx.x;
+    const TriRec t = tris[g];
+    const float4 lo4 = tlo[g], hi4 = thi[g];
+    const float lo[3] = {lo4.x, lo4.y, lo4.z}, hi[3] = {hi4.x, hi4.y, hi4.z};
+    const float e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    const v3 a = V3(t.v0x, t.v0y, t.v0z), b = V3(t.v1x, t.v1y, t.v1z), c = V3(t.v2x, t.v2y, t.v2z);
     const float emax = fmaxf(fmaxf(e[0], e[1]), e[2]);
-    // visits the cells of a (emax / div) grid over the box that the triangle passes through; returns how many
-    auto cells = [&](int div, bool write) {
+    const uint32_t w = WRITE ? offsets[g] : 0u;
+    // visits the cells of a (emax / div) grid over the box that the triangle passes through; returns how many (wave-uniform)
+    auto cells = [&](int div) {
         const float cell = emax / (float)div;
         int nc[3];
         for (int k = 0; k < 3; k++) {
             int m = (int)ceilf(e[k] / cell);
             nc[k] = m < 1 ? 1 : (m > div ? div : m);
         }
+        const int total = nc[0] * nc[1] * nc[2];
         uint32_t found = 0;
-        for (int iz = 0; iz < nc[2]; iz++)
-            for (int iy = 0; iy < nc[1]; iy++)
-                for (int ix = 0; ix < nc[0]; ix++) {
-                    const int idx[3] = {ix, iy, iz};
-                    float clo[3], chi[3], olo[3], ohi[3];
-                    for (int k = 0; k < 3; k++) {
-                        clo[k] = lo[k] + (float)idx[k] * cell;
-                        chi[k] = idx[k] + 1 == nc[k] ? hi[k] : lo[k] + (float)(idx[k] + 1) * cell;
-                    }
-                    if (!clip_bounds(a, b, c, clo, chi, olo, ohi)) continue;
-                    if (write) {
-                        out_tris[w + found] = t;
-                        out_lo[w + found] = make_float4(olo[0], olo[1], olo[2], 0.0f);
-                        out_hi[w + found] = make_float4(ohi[0], ohi[1], ohi[2], 0.0f);
-                    }
-                    found++;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int ci = c0 + (int)lane;
+            bool hit = false;
+            float olo[3], ohi[3];
+            if (ci < total) {
+                const int idx[3] = {ci % nc[0], (ci / nc[0]) % nc[1], ci / (nc[0] * nc[1])};
+                float clo[3], chi[3];
+                for (int k = 0; k < 3; k++) {
+                    clo[k] = lo[k] + (float)idx[k] * cell;
+                    chi[k] = idx[k] + 1 == nc[k] ? hi[k] : lo[k] + (float)(idx[k] + 1) * cell;
                 }
+                hit = clip_bounds(a, b, c, clo, chi, olo, ohi);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (WRITE && hit) {
+                const uint32_t pos = w + found + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                out_tris[pos] = t;
+                out_lo[pos] = make_float4(olo[0], olo[1], olo[2], 0.0f);
+                out_hi[pos] = make_float4(ohi[0], ohi[1], ohi[2], 0.0f);
+            }
+            found += (uint32_t)__popcll(m);
+        }
         return found;
     };
-    // an eighth of the longest side; a quarter if that gives too many pieces; else the triangle stays whole.  The write
-    // pass repeats the count pass's decision before it writes anything, so it never touches a neighbour's slots.
-    for (int div = 8; div >= 4; div >>= 1) {
-        const uint32_t found = cells(div, false);
-        if (found == 0) break;                                     // rounding left nothing: keep the triangle whole
-        if (found <= PT_SPLIT_MAX) {
-            if (WRITE) cells(div, true);
-            else counts[g] = found;
-            return;
-        }
+    if (WRITE) {
+        if (mode[g]) cells((int)mode[g]);        // 0: the candidate stays whole and k_split_copy_whole has written it
+        return;
     }
-    whole();
+    uint32_t pieces = 1u;
+    unsigned char md = 0;
+    for (int div = 8; div >= 4; div >>= 1) {
+        const uint32_t found = cells(div);
+        if (found == 0) break;                                     // rounding left nothing: keep the triangle whole
+        if (found <= PT_SPLIT_MAX) { pieces = found; md = (unsigned char)div; break; }
+    }
+    if (lane == 0) { counts[g] = pieces; mode[g] = md; }
+}
+
+// the triangles that stay whole, at their place among the references
+__global__ void k_split_copy_whole(uint32_t n, const TriRec* __restrict__ tris, const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                                   const unsigned char* __restrict__ mode, const uint32_t* __restrict__ offsets,
+                                   TriRec* __restrict__ out_tris, float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n || mode[g] != 0) return;
+    const uint32_t w = offsets[g];
+    out_tris[w] = tris[g];
+    out_lo[w] = tlo[g];
+    out_hi[w] = thi[g];
 }
 
 __device__ __forceinline__ unsigned long long spread21(uint32_t v)
@@ -919,30 +956,42 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     TriRec* src_tris = tris_tmp.p;
     float4 *src_lo = tlo.p, *src_hi = thi.p;
     if (!(flags & PT_BUILD_NO_SPLIT)) {
-        DevBuf<uint32_t> cnt, off;
+        DevBuf<uint32_t> cnt, off, cand, ncand;
+        DevBuf<unsigned char> mode;
         DevBuf<char> scan_tmp;
         PT_HIP(ctx, cnt.alloc(n));
         PT_HIP(ctx, off.alloc(n));
-        k_split<false><<<(n + B - 1) / B, B, 0, st>>>(n, tris_tmp.p, tlo.p, thi.p, bounds.p, cnt.p, nullptr, nullptr, nullptr, nullptr);
-        size_t scan_bytes = 0;
-        PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt.p, off.p, (int)n, st));
-        PT_HIP(ctx, scan_tmp.alloc(scan_bytes));
-        PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, cnt.p, off.p, (int)n, st));
-        uint32_t last[2];
-        PT_HIP(ctx, hipMemcpyAsync(&last[0], off.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        PT_HIP(ctx, hipMemcpyAsync(&last[1], cnt.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, cand.alloc(n));
+        PT_HIP(ctx, ncand.alloc(1));
+        PT_HIP(ctx, mode.alloc(n));
+        PT_HIP(ctx, hipMemsetAsync(ncand.p, 0, sizeof(uint32_t), st));
+        k_split_classify<<<(n + B - 1) / B, B, 0, st>>>(n, tris_tmp.p, tlo.p, thi.p, bounds.p, cnt.p, mode.p, cand.p, ncand.p);
+        uint32_t nsplit = 0;
+        PT_HIP(ctx, hipMemcpyAsync(&nsplit, ncand.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipStreamSynchronize(st));
-        const uint64_t nref = (uint64_t)last[0] + last[1];
-        if (nref > 0x0FFFFFFFull) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^28-1 triangle references after splitting");
-        if (nref > n) {
-            PT_HIP(ctx, tris_ref.alloc(nref));
-            PT_HIP(ctx, rlo.alloc(nref));
-            PT_HIP(ctx, rhi.alloc(nref));
-            k_split<true><<<(n + B - 1) / B, B, 0, st>>>(n, tris_tmp.p, tlo.p, thi.p, bounds.p, nullptr, off.p, tris_ref.p, rlo.p, rhi.p);
-            PT_HIP(ctx, hipStreamSynchronize(st));      // cnt / off go out of scope
-            src_tris = tris_ref.p; src_lo = rlo.p; src_hi = rhi.p;
-            n = (uint32_t)nref;
+        if (nsplit) {
+            k_split_cells<false><<<nsplit, 64, 0, st>>>(nsplit, cand.p, tris_tmp.p, tlo.p, thi.p, cnt.p, mode.p, nullptr, nullptr, nullptr, nullptr);
+            size_t scan_bytes = 0;
+            PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt.p, off.p, (int)n, st));
+            PT_HIP(ctx, scan_tmp.alloc(scan_bytes));
+            PT_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, cnt.p, off.p, (int)n, st));
+            uint32_t last[2];
+            PT_HIP(ctx, hipMemcpyAsync(&last[0], off.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipMemcpyAsync(&last[1], cnt.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            const uint64_t nref = (uint64_t)last[0] + last[1];
+            if (nref > 0x0FFFFFFFull) return set_error(ctx, PT_ERR_TOO_LARGE, "more than 2^28-1 triangle references after splitting");
+            if (nref > n) {
+                PT_HIP(ctx, tris_ref.alloc(nref));
+                PT_HIP(ctx, rlo.alloc(nref));
+                PT_HIP(ctx, rhi.alloc(nref));
+                k_split_copy_whole<<<(n + B - 1) / B, B, 0, st>>>(n, tris_tmp.p, tlo.p, thi.p, mode.p, off.p, tris_ref.p, rlo.p, rhi.p);
+                k_split_cells<true><<<nsplit, 64, 0, st>>>(nsplit, cand.p, tris_tmp.p, tlo.p, thi.p, cnt.p, mode.p, off.p, tris_ref.p, rlo.p, rhi.p);
+                src_tris = tris_ref.p; src_lo = rlo.p; src_hi = rhi.p;
+                n = (uint32_t)nref;
+            }
         }
+        PT_HIP(ctx, hipStreamSynchronize(st));      // the buffers of this block go out of scope
     }
     ctx->num_refs = n;
     stats.num_references = n;
