@@ -161,6 +161,11 @@ def main():
     r = ptdist.GpuRenderer(b, args.width, args.height, device)
     b.set_camera(cam)
     b.set_params(params)
+    # frames that share their launches (pt_set_batch, at most 8): the timed frames in equal batches, so that the run does not
+    # end on a short one (20 frames: 7 + 7 + 6 instead of 8 + 8 + 4)
+    per_rank = args.steps
+    nbatches = (per_rank + 7) // 8
+    b.set_batch(max(1, min(8, (per_rank + nbatches - 1) // nbatches)))
 
     def barrier():
         b.sync()
