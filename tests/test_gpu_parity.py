@@ -273,9 +273,10 @@ def test_hierarchy_is_well_formed(backend, cornell, flags):
     assert seen.all() and visited.all() and leaves == st.num_leaves
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 4])
 def test_both_builders_give_the_same_hits(backend, cornell, flags):
-    # 0 = agglomerative clustering, 1 = Morton radix tree only: the hierarchy must not change any result
+    # 0 = agglomerative clustering + surface-area-optimal collapse, 1 = Morton radix tree only, 4 = clustering with the greedy
+    # collapse: the hierarchy must not change any result
     backend.scene_upload(cornell)
     backend.build_accel(flags)
     rng = np.random.default_rng(31 + flags)
@@ -283,6 +284,30 @@ def test_both_builders_give_the_same_hits(backend, cornell, flags):
     o = oracle_lib.Oracle(cornell)
     hg, _ = backend.debug_intersect(rays)
     assert np.array_equal(hg, o.intersect(rays, use_bvh=True))
+
+
+def test_optimal_collapse_fills_the_nodes(backend):
+    """The surface-area-optimal choice of each wide node's children against the greedy one on the same clustered tree:
+    fewer and fuller nodes, lower cost, leaves of at most four triangles, the same hits."""
+    sc = procedural.sponza_class(detail=0.2)
+    backend.scene_upload(sc)
+    rng = np.random.default_rng(3)
+    rays = random_rays(rng, 20000, [-14, 0.3, -8], [14, 10.5, 8])
+    shapes = {}
+    for flags in (4, 0):
+        st = backend.build_accel(flags)
+        nodes, tris = backend.debug_read_bvh()
+        child = nodes[:, 4:12]
+        empty = child == M32
+        leaf = ((child >> 31) == 1) & ~empty
+        hits, counters = backend.debug_intersect(rays)
+        shapes[flags] = (st.num_nodes, st.sah_cost, (~empty).sum(1).mean(), hits, counters)
+        assert ((((child[leaf] >> 28) & 7) + 1) <= 4).all()
+        assert int((((child[leaf] >> 28) & 7) + 1).sum()) == st.num_references == len(tris)
+    greedy, optimal = shapes[4], shapes[0]
+    assert np.array_equal(greedy[3], optimal[3])
+    assert optimal[0] < 0.9 * greedy[0] and optimal[1] < 0.92 * greedy[1] and optimal[2] > greedy[2] + 1.5
+    assert optimal[4][1] < 0.85 * greedy[4][1]           # triangle tests for the same rays
 
 
 # ---- frames --------------------------------------------------------------------------------------------------
