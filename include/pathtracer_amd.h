@@ -117,7 +117,7 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* scene);
 #define PT_BUILD_DEFAULT 0u
 #define PT_BUILD_LBVH 1u       /* Morton-order hierarchy only (no agglomerative refinement) */
 #define PT_BUILD_GREEDY 4u     /* children of a wide node chosen greedily (largest box first) instead of by the surface-area-optimal
-                                * dynamic programme: the round-1 hierarchy, kept for comparison */
+                                * dynamic programme: kept for comparison */
 #define PT_BUILD_NO_SPLIT 2u   /* every triangle is entered once; by default large triangles whose boxes are mostly empty are
                                 * entered once per cell they pass through (same hits, tighter boxes) */
 int pt_build_accel(pt_ctx* ctx, uint32_t flags, pt_accel_stats* stats);
