@@ -135,8 +135,8 @@ static int finish_timing(pt_ctx* ctx)
         t.nodes_visited = hs[0];
         t.tris_tested = hs[1];
         if (getenv("PT_WAVE_STATS"))
-            fprintf(stderr, "wave stats: node phases %llu (lanes %llu, %.1f/64), leaf phases %llu (lanes %llu, %.1f/64), refills %llu, wave ms: draining %.1f of resident %.1f, longest ray %llu steps; node phases by active lanes <=8: %llu, <=16: %llu, <=32: %llu, <=64: %llu\n",
-                    hs[3], hs[4], hs[3] ? (double)hs[4] / hs[3] : 0.0, hs[5], hs[6], hs[5] ? (double)hs[6] / hs[5] : 0.0, hs[7], hs[8] * 1e-5, hs[9] * 1e-5, hs[10], hs[11], hs[12], hs[13], hs[14]);
+            fprintf(stderr, "wave stats: node phases %llu (lanes %llu, %.1f/64), lanes without a ray %.1f/64, leaf phases %llu (lanes %llu, %.1f/64), refills %llu, wave ms: draining %.1f of resident %.1f, longest ray %llu steps; node phases by active lanes <=8: %llu, <=16: %llu, <=32: %llu, <=64: %llu\n",
+                    hs[3], hs[4], hs[3] ? (double)hs[4] / hs[3] : 0.0, hs[3] ? (double)hs[15] / hs[3] : 0.0, hs[5], hs[6], hs[5] ? (double)hs[6] / hs[5] : 0.0, hs[7], hs[8] * 1e-5, hs[9] * 1e-5, hs[10], hs[11], hs[12], hs[13], hs[14]);
         const char* path = getenv("PT_WAVE_TRACE");
         if (path && ctx->d_wave_trace) {
             size_t len = (size_t)ctx->wave_trace_rounds * ctx->wave_trace_waves * 4;

@@ -65,6 +65,7 @@ struct WaveStats {
     uint32_t node_phases = 0, node_lanes = 0;      // node phases run, lanes active in them
     uint32_t leaf_phases = 0, leaf_lanes = 0;
     uint32_t refills = 0;
+    uint32_t idle_lanes = 0;                       // lanes without a ray during node phases (the others not on a node wait with a leaf)
     uint32_t node_hist[4] = {0, 0, 0, 0};          // node phases with <= 8, 9..16, 17..32, 33..64 active lanes
     uint32_t longest_ray = 0;                      // loop iterations the longest-lived ray of this wave stayed in flight
     unsigned long long t_start = 0, t_exhausted = 0, t_end = 0;   // t_exhausted: the queue ran dry, only own rays left
@@ -478,10 +479,11 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
         // node phase: every lane standing on an internal node takes one step
         bool at_node = has && s.cur < PT_CUR_NONE;
         if (STATS && wave_stats) {
-            unsigned long long nm = __ballot(at_node);
+            unsigned long long nm = __ballot(at_node), im = __ballot(!has);
             if (lane == 0 && nm) {
                 uint32_t c = (uint32_t)__popcll(nm);
                 wave_stats->node_phases++; wave_stats->node_lanes += c;
+                wave_stats->idle_lanes += (uint32_t)__popcll(im);
                 wave_stats->node_hist[c <= 8 ? 0 : c <= 16 ? 1 : c <= 32 ? 2 : 3]++;
             }
         }

@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
             atomicAdd(&stats[9], ws.t_end - ws.t_start);
             atomicMax(&stats[10], (unsigned long long)ws.longest_ray);
             for (int k = 0; k < 4; k++) atomicAdd(&stats[11 + k], (unsigned long long)ws.node_hist[k]);
+            atomicAdd(&stats[15], (unsigned long long)ws.idle_lanes);
             if (wave_trace) {
                 unsigned long long* w = wave_trace + (size_t)blockIdx.x * 4;
                 w[0] = ws.t_start; w[1] = ws.t_exhausted; w[2] = ws.t_end;
