@@ -15,7 +15,7 @@
 //      b. PT_BUILD_LBVH: binary radix tree over the sorted codes (Karras 2012, k_karras) and bottom-up
 //         boxes with an arrival counter per node (k_refit).  Fastest build, about 1.6x the traversal cost.
 //   5. k_collapse_dp  which subtrees become the children of an 8-wide node: surface-area-optimal, by a dynamic programme
-//                     over the binary tree (clustered trees; PT_BUILD_GREEDY or PT_BUILD_LBVH: open the largest box first)
+//                     over the binary tree (PT_BUILD_GREEDY: open the largest box first)
 //      k_collapse     level by level: binary tree -> 8-wide nodes of 128 bytes with 8-bit quantised child
 //                     boxes, leaves of <= 4 triangles, triangles are written out in leaf order
 #include "pt_context.h"
@@ -357,6 +357,36 @@ __global__ void k_karras(int n, const unsigned long long* __restrict__ keys, uin
 }
 
 // b2lo.w carries the subtree's triangle count (as bits)
+// Hand-off between threads of one launch (bottom-up passes over the radix tree: whoever arrives second at a node reads what
+// the first one wrote).  The L2 of each XCD is not coherent with the others', and a release fence per node writes a whole L2
+// back (two such fences per node made these passes take 19 ms each for 3 M triangles).  Instead the handed-over words are
+// stored and loaded at agent scope (write-through / read-through), the writer waits for its stores before it announces its
+// arrival with an agent-scope atomic, and the reader's loads follow that atomic in program order.
+__device__ __forceinline__ void st_agent(float4* p, float4 v)
+{
+    union { float4 f; unsigned long long u[2]; } x;
+    x.f = v;
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, x.u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, x.u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld_agent(const float4* p)
+{
+    union { float4 f; unsigned long long u[2]; } x;
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float4*>(p));
+    x.u[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x.u[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return x.f;
+}
+// true when this thread is the second to arrive at the node (and goes on with it); its own stores have landed before
+__device__ __forceinline__ bool arrive_second(uint32_t* flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t old = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");
+    return old != 0;
+}
+
 __global__ void k_refit(int n, const uint32_t* __restrict__ vals, const float4* __restrict__ tlo, const float4* __restrict__ thi,
                         const uint2* __restrict__ children, const uint32_t* __restrict__ parent, uint32_t* flags,
                         float4* b2lo, float4* b2hi)
@@ -367,23 +397,20 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals, const float4* 
     float4 lo = tlo[t], hi = thi[t];
     uint32_t node = (uint32_t)(n - 1 + j);
     lo.w = __uint_as_float(1u);
-    b2lo[node] = lo;
-    b2hi[node] = hi;
+    st_agent(&b2lo[node], lo);
+    st_agent(&b2hi[node], hi);
     if (n == 1) return;
     uint32_t cur = parent[node];
     while (cur != NONE) {
-        __threadfence();                       // publish this subtree's box before announcing arrival
-        uint32_t old = atomicAdd(&flags[cur], 1u);
-        if (old == 0) return;                  // the sibling subtree is not finished: its thread continues
-        __threadfence();                       // see the sibling's box
+        if (!arrive_second(&flags[cur])) return;     // the sibling subtree is not finished: its thread continues
         uint2 ch = children[cur];
-        float4 llo = b2lo[ch.x], lhi = b2hi[ch.x];
-        float4 rlo = b2lo[ch.y], rhi = b2hi[ch.y];
+        float4 llo = ld_agent(&b2lo[ch.x]), lhi = ld_agent(&b2hi[ch.x]);
+        float4 rlo = ld_agent(&b2lo[ch.y]), rhi = ld_agent(&b2hi[ch.y]);
         float4 nlo = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z),
                                  __uint_as_float(__float_as_uint(llo.w) + __float_as_uint(rlo.w)));
         float4 nhi = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
-        b2lo[cur] = nlo;
-        b2hi[cur] = nhi;
+        st_agent(&b2lo[cur], nlo);
+        st_agent(&b2hi[cur], nhi);
         cur = parent[cur];
     }
 }
@@ -571,7 +598,7 @@ __device__ __forceinline__ void store_child_planes(Node8& nd, int k, const uint3
 #endif
 // per internal node of the binary tree: c(n, 1..7) and the choices behind them.  choice bits: 3 * (j - 2) + {0, 1, 2} =
 // k of split(n, j), j = 2..8; bit 21 = a leaf is cheaper than a node; bit 22 + (i - 2) = c(n, i) takes c(n, i - 1), i = 2..7
-struct CollapseDp { float c[7]; uint32_t choice; };
+struct alignas(16) CollapseDp { float c[7]; uint32_t choice; };
 
 __device__ __forceinline__ float dp_area(float4 lo, float4 hi)
 {
@@ -580,21 +607,22 @@ __device__ __forceinline__ float dp_area(float4 lo, float4 hi)
     return ex * ey + ey * ez + ez * ex;
 }
 
-// nodes [first, first + count) of the binary tree, whose children are leaves or have smaller numbers than first
-__global__ void k_collapse_dp(uint32_t first, uint32_t count, int n, uint32_t root, const uint2* __restrict__ children,
-                              const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, CollapseDp* dp)
+// c(n, .) and the choices of internal node id of the binary tree; its children's are final.  AGENT: the children's records
+// were written by other threads of this launch (see st_agent)
+template <bool AGENT>
+__device__ void collapse_dp_node(uint32_t id, int n, float inv_root, const uint2* __restrict__ children,
+                                 const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, CollapseDp* dp)
 {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= count) return;
-    const uint32_t id = first + g;
-    float root_area = dp_area(b2lo[root], b2hi[root]);
-    const float inv_root = root_area > 0.0f ? 1.0f / root_area : 1.0f;
     const uint2 ch = children[id];
     float cl[8], cr[8];
     auto load = [&](uint32_t c, float* out) {
         if (c >= (uint32_t)(n - 1)) {
             float v = dp_area(b2lo[c], b2hi[c]) * inv_root * (PT_COST_LEAF + PT_COST_TRI);
             for (int i = 1; i < 8; i++) out[i] = v;
+        } else if (AGENT) {
+            const float4* rec = reinterpret_cast<const float4*>(dp + c);
+            float4 a = ld_agent(rec), b = ld_agent(rec + 1);
+            out[1] = a.x; out[2] = a.y; out[3] = a.z; out[4] = a.w; out[5] = b.x; out[6] = b.y; out[7] = b.z;
         } else {
             for (int i = 1; i < 8; i++) out[i] = dp[c].c[i - 1];
         }
@@ -626,7 +654,44 @@ __global__ void k_collapse_dp(uint32_t first, uint32_t count, int n, uint32_t ro
         else r.c[i - 1] = split[i];
     }
     r.choice = choice;
-    dp[id] = r;
+    if (AGENT) {
+        float4* rec = reinterpret_cast<float4*>(dp + id);
+        st_agent(rec, make_float4(r.c[0], r.c[1], r.c[2], r.c[3]));
+        st_agent(rec + 1, make_float4(r.c[4], r.c[5], r.c[6], __uint_as_float(choice)));
+    } else {
+        dp[id] = r;
+    }
+}
+
+__device__ __forceinline__ float dp_inv_root(uint32_t root, const float4* __restrict__ b2lo, const float4* __restrict__ b2hi)
+{
+    float root_area = dp_area(b2lo[root], b2hi[root]);
+    return root_area > 0.0f ? 1.0f / root_area : 1.0f;
+}
+
+// clustered trees: nodes [first, first + count), whose children are leaves or have smaller numbers than first (the nodes of
+// one clustering round)
+__global__ void k_collapse_dp(uint32_t first, uint32_t count, int n, uint32_t root, const uint2* __restrict__ children,
+                              const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, CollapseDp* dp)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    collapse_dp_node<false>(first + g, n, dp_inv_root(root, b2lo, b2hi), children, b2lo, b2hi, dp);
+}
+
+// Morton radix trees: bottom-up from every leaf, the second thread to arrive at a node computes it (flags zeroed)
+__global__ void k_collapse_dp_up(int n, uint32_t root, const uint2* __restrict__ children, const uint32_t* __restrict__ parent, uint32_t* flags,
+                                 const float4* __restrict__ b2lo, const float4* __restrict__ b2hi, CollapseDp* dp)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || n == 1) return;
+    const float inv_root = dp_inv_root(root, b2lo, b2hi);
+    uint32_t cur = parent[(uint32_t)(n - 1 + j)];
+    while (cur != NONE) {
+        if (!arrive_second(&flags[cur])) return;     // the sibling subtree is not finished: its thread continues
+        collapse_dp_node<true>(cur, n, inv_root, children, b2lo, b2hi, dp);
+        cur = parent[cur];
+    }
 }
 
 // one thread per frontier item: builds one Node8 and queues its internal children.  dp == nullptr: greedy choice of the
@@ -1018,13 +1083,44 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
     PT_HIP(ctx, sort_tmp.alloc(tmp_bytes));
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
-    uint32_t root_id = 0;   // binary-tree node ids: internal 0..n-2, leaf j -> (n-1)+j
-    if (flags & PT_BUILD_LBVH) {
+    // Binary tree over the sorted references (node ids: internal 0..n-2, leaf j -> (n-1)+j).  Two candidates: agglomerative
+    // clustering and the plain Morton radix tree.  Clustering gives the better hierarchy for surfaces (architecture, terrain:
+    // 6 to 25 % lower cost); for unstructured clouds of small primitives (foliage) the radix tree comes out ahead (the large
+    // test scene: cost 67.0 against 67.8, 9 % more rays per second).  By default both are built and the one whose
+    // surface-area-optimal collapse is cheaper (c(root, 1) of k_collapse_dp) is kept; the radix tree adds about a fifth to
+    // the build time.  PT_BUILD_LBVH / PT_BUILD_CLUSTER build one of them only.
+    const bool greedy = (flags & PT_BUILD_GREEDY) != 0;
+    const bool want_radix = (flags & PT_BUILD_LBVH) || (!(flags & PT_BUILD_CLUSTER) && !greedy && n > 1);
+    const bool want_cluster = !(flags & PT_BUILD_LBVH);
+    uint32_t root_id = 0;
+    DevBuf<uint2> children_r;                  // the radix tree when both are built
+    DevBuf<float4> b2lo_r, b2hi_r;
+    DevBuf<CollapseDp> dp_r;
+    uint2* children_p = children.p;
+    float4 *b2lo_p = b2lo.p, *b2hi_p = b2hi.p;
+    CollapseDp* dp_p = nullptr;
+    if (want_radix) {
+        uint2* ch = children.p;
+        float4 *lo2 = b2lo.p, *hi2 = b2hi.p;
+        DevBuf<CollapseDp>* dpb = &dp;
+        if (want_cluster) {
+            PT_HIP(ctx, children_r.alloc(n));
+            PT_HIP(ctx, b2lo_r.alloc(2 * (size_t)n));
+            PT_HIP(ctx, b2hi_r.alloc(2 * (size_t)n));
+            ch = children_r.p; lo2 = b2lo_r.p; hi2 = b2hi_r.p; dpb = &dp_r;
+        }
         PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
         PT_HIP(ctx, hipMemsetAsync(parent.p, 0xFF, 2 * (size_t)n * sizeof(uint32_t), st));
-        if (n > 1) k_karras<<<G, B, 0, st>>>((int)n, keys_sorted.p, children.p, parent.p);
-        k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, src_lo, src_hi, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p);
-    } else {
+        if (n > 1) k_karras<<<G, B, 0, st>>>((int)n, keys_sorted.p, ch, parent.p);
+        k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, src_lo, src_hi, ch, parent.p, flagsb.p, lo2, hi2);
+        if (n > 1 && !greedy) {
+            PT_HIP(ctx, dpb->alloc(n));
+            PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
+            k_collapse_dp_up<<<G, B, 0, st>>>((int)n, 0u, ch, parent.p, flagsb.p, lo2, hi2, dpb->p);
+        }
+        children_p = ch; b2lo_p = lo2; b2hi_p = hi2; dp_p = dpb->p;      // the radix tree's root is node 0
+    }
+    if (want_cluster) {
         DevBuf<uint32_t> cid[2], nearest, totals;
         DevBuf<unsigned long long> pflags, pscan;
         DevBuf<char> scan_tmp;
@@ -1057,11 +1153,23 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
             cur ^= 1;
             if (++rounds > 4096) return set_error(ctx, PT_ERR_INVALID, "hierarchy build: clustering did not terminate");
         }
-        root_id = n > 1 ? next_id - 1 : 0;   // the last node created is the root
-        if (n > 1 && !(flags & PT_BUILD_GREEDY)) {
+        const uint32_t cluster_root = n > 1 ? next_id - 1 : 0;   // the last node created is the root
+        if (n > 1 && !greedy) {
             PT_HIP(ctx, dp.alloc(n));
             for (auto& r : dp_rounds)
-                k_collapse_dp<<<(r.second + B - 1) / B, B, 0, st>>>(r.first, r.second, (int)n, root_id, children.p, b2lo.p, b2hi.p, dp.p);
+                k_collapse_dp<<<(r.second + B - 1) / B, B, 0, st>>>(r.first, r.second, (int)n, cluster_root, children.p, b2lo.p, b2hi.p, dp.p);
+        }
+        bool keep_cluster = true;
+        if (want_radix && n > 1 && !greedy) {
+            float cost_c = 0.0f, cost_r = 0.0f;
+            PT_HIP(ctx, hipMemcpyAsync(&cost_c, &dp.p[cluster_root].c[0], sizeof(float), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipMemcpyAsync(&cost_r, &dp_r.p[0].c[0], sizeof(float), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            keep_cluster = !(cost_r < cost_c);
+        }
+        if (keep_cluster) {
+            children_p = children.p; b2lo_p = b2lo.p; b2hi_p = b2hi.p; dp_p = greedy ? nullptr : dp.p;
+            root_id = cluster_root;
         }
     }
 
@@ -1078,7 +1186,7 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         ctx->level_start.push_back(ctx->level_start.back() + nitems);
         PT_HIP(ctx, hipMemsetAsync(counters.p + 2 + (cur ^ 1), 0, sizeof(uint32_t), st));
         k_collapse<<<(nitems + 63) / 64, 64, 0, st>>>(nitems, fr[cur].p, fr[cur ^ 1].p, counters.p + 2 + (cur ^ 1), counters.p, counters.p + 1,
-                                                     (int)n, children.p, b2lo.p, b2hi.p, vals_sorted.p, src_tris, ctx->d_tris, ctx->d_nodes, pad, dp.p);
+                                                     (int)n, children_p, b2lo_p, b2hi_p, vals_sorted.p, src_tris, ctx->d_tris, ctx->d_nodes, pad, dp_p);
         PT_HIP(ctx, hipMemcpyAsync(&nitems, counters.p + 2 + (cur ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipStreamSynchronize(st));
         cur ^= 1;

@@ -273,10 +273,11 @@ def test_hierarchy_is_well_formed(backend, cornell, flags):
     assert seen.all() and visited.all() and leaves == st.num_leaves
 
 
-@pytest.mark.parametrize("flags", [0, 1, 4])
+@pytest.mark.parametrize("flags", [0, 1, 8, 4, 5])
 def test_both_builders_give_the_same_hits(backend, cornell, flags):
-    # 0 = agglomerative clustering + surface-area-optimal collapse, 1 = Morton radix tree only, 4 = clustering with the greedy
-    # collapse: the hierarchy must not change any result
+    # 0 = the cheaper of the clustered tree and the Morton radix tree, 1 = radix tree only, 8 = clustering only (each with the
+    # surface-area-optimal collapse), 4 / 5 = clustering / radix tree with the greedy collapse: the hierarchy must not change
+    # any result
     backend.scene_upload(cornell)
     backend.build_accel(flags)
     rng = np.random.default_rng(31 + flags)
