@@ -115,9 +115,10 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* scene);
 /* CreateAccelerationStructure() (RayTracingLayer.cpp:342-348): GPU build of the hierarchy
  * that replaces the driver's BLAS/TLAS (binding 0).  flags: PT_BUILD_* below. */
 #define PT_BUILD_DEFAULT 0u
-#define PT_BUILD_LBVH 1u       /* Morton radix tree only (fastest build).  By default the builder makes this tree and the
-                                * agglomeratively clustered one and keeps the one with the lower surface-area cost */
-#define PT_BUILD_CLUSTER 8u    /* agglomerative clustering only */
+#define PT_BUILD_CLUSTER 8u    /* agglomerative clustering instead of the default tree (Morton radix tree + treelet restructuring) */
+#define PT_BUILD_LBVH 1u       /* with PT_BUILD_CLUSTER: build both trees and keep the one with the lower surface-area cost */
+#define PT_BUILD_NO_TREELET 16u /* no treelet restructuring passes (seven subtrees at a time, cheapest topology by summed box
+                                * area) over the binary tree: PT_BUILD_NO_TREELET alone is the fastest build */
 #define PT_BUILD_GREEDY 4u     /* children of a wide node chosen greedily (largest box first) instead of by the surface-area-optimal
                                 * dynamic programme: kept for comparison */
 #define PT_BUILD_NO_SPLIT 2u   /* every triangle is entered once; by default large triangles whose boxes are mostly empty are

@@ -7,13 +7,16 @@
 //   1b. k_split_*     large triangles whose boxes are mostly empty are entered once per cell they pass through (one wave per such triangle)
 //   2. k_morton       63-bit Morton code of the box centre
 //   3. radix sort     (rocPRIM via hipcub) of (code, triangle)
-//   4. binary hierarchy, one of
-//      a. agglomerative (default): parallel locally-ordered clustering -- every cluster looks PLOC_RADIUS
-//         places left and right in Morton order for the neighbour that gives the smallest merged box,
-//         mutual nearest neighbours merge, the cluster list is compacted with a prefix scan, repeat until
-//         one cluster is left (k_ploc_nearest, k_ploc_flags, scan, k_ploc_merge).  Near-SAH quality.
-//      b. PT_BUILD_LBVH: binary radix tree over the sorted codes (Karras 2012, k_karras) and bottom-up
-//         boxes with an arrival counter per node (k_refit).  Fastest build, about 1.6x the traversal cost.
+//   4. binary hierarchy
+//      a. default: binary radix tree over the sorted codes (Karras 2012, k_karras), bottom-up boxes with an arrival
+//         counter per node (k_refit), then treelet restructuring passes (Karras and Aila 2013, k_treelet_up): every
+//         treelet of seven subtrees is put into the topology with the smallest summed box area.  PT_BUILD_NO_TREELET
+//         leaves the passes out (fastest build).
+//      b. PT_BUILD_CLUSTER: parallel locally-ordered clustering -- every cluster looks PLOC_RADIUS places left and
+//         right in Morton order for the neighbour that gives the smallest merged box, mutual nearest neighbours
+//         merge, the cluster list is compacted with a prefix scan, repeat until one cluster is left
+//         (k_ploc_nearest, k_ploc_flags, scan, k_ploc_merge); the same treelet passes follow.
+//      With PT_BUILD_CLUSTER | PT_BUILD_LBVH both are built and the one the collapse below prices cheaper is kept.
 //   5. k_collapse_dp  which subtrees become the children of an 8-wide node: surface-area-optimal, by a dynamic programme
 //                     over the binary tree (PT_BUILD_GREEDY: open the largest box first)
 //      k_collapse     level by level: binary tree -> 8-wide nodes of 128 bytes with 8-bit quantised child
@@ -415,6 +418,254 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals, const float4* 
     }
 }
 
+
+// ---- treelet restructuring (after Karras and Aila, "Fast parallel construction of high-quality bounding volume
+// hierarchies", 2013) -----------------------------------------------------------------------------------------------
+// Bottom-up over a binary tree: at every node with at least seven triangles below it, the node and the five descendants with
+// the largest boxes are taken out (a treelet of six internal nodes over seven subtrees) and put back in the topology that
+// minimises the summed box area of the six, found by a dynamic programme over the 127 subsets of the seven subtrees.
+// One lane per leaf climbs the tree; the treelets the lanes of a wave arrive at are restructured one after the other by the
+// whole wave (subsets and their partitions dealt out over the lanes).  Data is handed between waves like in the other
+// bottom-up passes (st_agent / ld_agent).
+#define PT_TREELET_LEAVES 7
+#ifndef PT_TREELET_PASSES
+#define PT_TREELET_PASSES 2
+#endif
+__device__ __forceinline__ float dp_area(float4 lo, float4 hi);
+
+__device__ __forceinline__ uint2 ld_agent2(const uint2* p)
+{
+    union { uint2 v; unsigned long long u; } x;
+    x.u = __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<uint2*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return x.v;
+}
+__device__ __forceinline__ void st_agent2(uint2* p, uint2 v)
+{
+    union { uint2 v; unsigned long long u; } x;
+    x.v = v;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), x.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the subsets of seven elements in order of their size: v[first[k] .. first[k + 1]) are those with k elements
+struct SubsetTable { unsigned char v[128]; unsigned char first[9]; };
+constexpr SubsetTable make_subset_table()
+{
+    SubsetTable t{};
+    int at = 0;
+    for (int k = 0; k <= 7; k++) {
+        t.first[k] = (unsigned char)at;
+        for (int sset = 0; sset < 128; sset++) {
+            int pc = 0;
+            for (int b = 0; b < 7; b++) pc += (sset >> b) & 1;
+            if (pc == k) t.v[at++] = (unsigned char)sset;
+        }
+    }
+    t.first[8] = (unsigned char)at;
+    return t;
+}
+__constant__ SubsetTable c_subsets = make_subset_table();
+
+struct TreeletLds {
+    float area[128], cost[128];
+    unsigned char part[128];
+    float lo[PT_TREELET_LEAVES][3], hi[PT_TREELET_LEAVES][3];
+    uint32_t count[PT_TREELET_LEAVES], leaf[PT_TREELET_LEAVES], inner[PT_TREELET_LEAVES - 1];
+    unsigned char node_set[PT_TREELET_LEAVES - 1], node_kid[PT_TREELET_LEAVES - 1][2];
+    float cur_cost;
+    int ok;
+};
+
+// bits of i spread over the set bits of mask, lowest first
+__device__ __forceinline__ int deposit_bits(int i, int mask)
+{
+    int r = 0;
+#pragma unroll
+    for (int b = 0; b < PT_TREELET_LEAVES - 1; b++) {
+        int low = mask & -mask;
+        if (i & (1 << b)) r |= low;
+        mask ^= low;
+    }
+    return r;
+}
+
+// all 64 lanes of the wave (one workgroup) restructure the treelet rooted at R
+__device__ void treelet_optimize(uint32_t R, int lane, int n, uint2* children, uint32_t* parent, float4* b2lo, float4* b2hi, TreeletLds& S)
+{
+    constexpr int NL = PT_TREELET_LEAVES;
+    constexpr int FULL = (1 << NL) - 1;
+    // the treelet: expand the subtree with the largest box until there are seven (one lane; the loads of a step go out together)
+    if (lane == 0) {
+        uint2 kids[NL];                    // children of subtree k when it is an internal node
+        float larea[NL];
+        auto load_leaf = [&](int k, uint32_t id) {
+            S.leaf[k] = id;
+            float4 lo = ld_agent(&b2lo[id]), hi = ld_agent(&b2hi[id]);
+            kids[k] = id < (uint32_t)(n - 1) ? ld_agent2(&children[id]) : make_uint2(NONE, NONE);
+            S.lo[k][0] = lo.x; S.lo[k][1] = lo.y; S.lo[k][2] = lo.z;
+            S.hi[k][0] = hi.x; S.hi[k][1] = hi.y; S.hi[k][2] = hi.z;
+            S.count[k] = __float_as_uint(lo.w);
+            larea[k] = dp_area(lo, hi);
+        };
+        S.inner[0] = R;
+        int ni = 1, nl = 2;
+        float cur_cost = dp_area(ld_agent(&b2lo[R]), ld_agent(&b2hi[R]));
+        uint2 ch = ld_agent2(&children[R]);
+        load_leaf(0, ch.x);
+        load_leaf(1, ch.y);
+        while (nl < NL) {
+            int best = -1;
+            float ba = -1.0f;
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (k < nl && kids[k].x != NONE && larea[k] > ba) { ba = larea[k]; best = k; }
+            if (best < 0) break;                    // fewer than seven subtrees: leave it
+            uint2 c2 = make_uint2(NONE, NONE);
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (k == best) { c2 = kids[k]; S.inner[ni] = S.leaf[k]; }
+            ni++;
+            cur_cost += ba;
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (k == best) load_leaf(k, c2.x);
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (k == nl) load_leaf(k, c2.y);
+            nl++;
+        }
+        S.cur_cost = cur_cost;
+        S.ok = nl == NL;
+    }
+    __syncthreads();
+    if (!S.ok) { __syncthreads(); return; }
+    // box area of every subset: two per lane
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int sset = lane + 64 * h;
+        float lo[3] = {3.4028235e38f, 3.4028235e38f, 3.4028235e38f}, hi[3] = {-3.4028235e38f, -3.4028235e38f, -3.4028235e38f};
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if ((sset & (1 << k)) && S.lo[k][0] <= S.hi[k][0]) {       // not the empty box of triangles that cannot be hit
+#pragma unroll
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], S.lo[k][a]); hi[a] = fmaxf(hi[a], S.hi[k][a]); }
+            }
+        S.area[sset] = dp_area(make_float4(lo[0], lo[1], lo[2], 0.0f), make_float4(hi[0], hi[1], hi[2], 0.0f));
+        S.cost[sset] = 0.0f;               // single subtrees cost nothing here; the others are overwritten below
+    }
+    __syncthreads();
+    // cheapest topology of every subset, by size: cost = own box + the two parts'.  2^g lanes share the partitions of a subset
+#pragma unroll
+    for (int k = 2; k <= NL; k++) {
+        const int gl = k <= 4 ? 0 : k == 5 ? 1 : k == 6 ? 3 : 6;
+        const int idx = lane >> gl, q = lane & ((1 << gl) - 1);
+        const int nsub = (int)c_subsets.first[k + 1] - (int)c_subsets.first[k];
+        const bool active = idx < nsub;
+        const int sset = active ? (int)c_subsets.v[c_subsets.first[k] + idx] : 3;
+        const int low = sset & -sset, rest = sset ^ low;
+        const int nparts = (1 << (k - 1)) - 1;        // the parts that hold the lowest element, the whole set left out
+        float best = __builtin_inff();
+        int bp = FULL;
+        for (int i = q; i < nparts; i += 1 << gl) {
+            const int pp = low | deposit_bits(i, rest);
+            const float c = S.cost[pp] + S.cost[sset ^ pp];
+            if (c < best || (c == best && pp < bp)) { best = c; bp = pp; }
+        }
+        for (int off = (1 << gl) >> 1; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off);
+            const int op = __shfl_xor(bp, off);
+            if (ob < best || (ob == best && op < bp)) { best = ob; bp = op; }
+        }
+        if (active && q == 0) { S.cost[sset] = S.area[sset] + best; S.part[sset] = (unsigned char)bp; }
+        __syncthreads();
+    }
+    if (!(S.cost[FULL] < S.cur_cost * 0.9999f)) { __syncthreads(); return; }
+    // the six internal nodes in that topology: node t covers node_set[t]; a child is subtree (0x80 | k) or internal node t'
+    if (lane == 0) {
+        int sp = 1, next = 1;
+        S.node_set[0] = (unsigned char)FULL;
+        // the stack of (subset, node) pairs to do: a byte per entry in two 64-bit words, so that it stays in registers
+        unsigned long long stack_sets = FULL, stack_ts = 0;
+        while (sp) {
+            sp--;
+            const int sset = (int)((stack_sets >> (8 * sp)) & 0xFF), t = (int)((stack_ts >> (8 * sp)) & 0xFF);
+            const int pp = S.part[sset];
+            const int sub[2] = {pp, sset ^ pp};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if ((sub[h] & (sub[h] - 1)) == 0) {
+                    S.node_kid[t][h] = (unsigned char)(0x80 | (__ffs(sub[h]) - 1));
+                } else {
+                    S.node_kid[t][h] = (unsigned char)next;
+                    S.node_set[next] = (unsigned char)sub[h];
+                    stack_sets = (stack_sets & ~(0xFFull << (8 * sp))) | ((unsigned long long)sub[h] << (8 * sp));
+                    stack_ts = (stack_ts & ~(0xFFull << (8 * sp))) | ((unsigned long long)next << (8 * sp));
+                    sp++;
+                    next++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (lane < NL - 1) {
+        const int sset = S.node_set[lane];
+        const uint32_t X = S.inner[lane];
+        uint32_t kid[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int ref = S.node_kid[lane][h];
+            kid[h] = (ref & 0x80) ? S.leaf[ref & 7] : S.inner[ref];
+            __hip_atomic_store(&parent[kid[h]], X, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        st_agent2(&children[X], make_uint2(kid[0], kid[1]));
+        float lo[3] = {3.4028235e38f, 3.4028235e38f, 3.4028235e38f}, hi[3] = {-3.4028235e38f, -3.4028235e38f, -3.4028235e38f};
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (sset & (1 << k)) {
+                cnt += S.count[k];
+                if (!(S.lo[k][0] <= S.hi[k][0])) continue;
+#pragma unroll
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], S.lo[k][a]); hi[a] = fmaxf(hi[a], S.hi[k][a]); }
+            }
+        st_agent(&b2lo[X], make_float4(lo[0], lo[1], lo[2], __uint_as_float(cnt)));
+        st_agent(&b2hi[X], make_float4(hi[0], hi[1], hi[2], 0.0f));
+    }
+    __syncthreads();
+}
+
+// one pass (flags zeroed), workgroups of one wave: every lane climbs from its leaf; whoever arrives second at a node owns its
+// treelet, and the wave restructures the treelets its lanes own one after the other before those lanes climb on
+__global__ __launch_bounds__(64) void k_treelet_up(int n, uint2* children, uint32_t* parent, uint32_t* flags, float4* b2lo, float4* b2hi)
+{
+    __shared__ TreeletLds S;
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 64 + lane;
+    uint32_t cur = (j < n && n > 1) ? parent[(uint32_t)(n - 1 + j)] : NONE;
+    for (;;) {
+        if (cur != NONE && !arrive_second(&flags[cur])) cur = NONE;
+        unsigned long long m = __ballot(cur != NONE);
+        if (!m) break;
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)cur, src);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(ld_agent(&b2lo[R]).w)) >= (uint32_t)PT_TREELET_LEAVES)
+                treelet_optimize(R, lane, n, children, parent, b2lo, b2hi, S);
+        }
+        if (cur != NONE) cur = __hip_atomic_load(&parent[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// parent pointers of a binary tree given by its children (the clustered tree is built without them)
+__global__ void k_parents(int n, uint32_t root, const uint2* __restrict__ children, uint32_t* __restrict__ parent)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    uint2 ch = children[i];
+    parent[ch.x] = (uint32_t)i;
+    parent[ch.y] = (uint32_t)i;
+    if ((uint32_t)i == root) parent[i] = NONE;
+}
 
 // ---- agglomerative build (parallel locally-ordered clustering) ------------------------------------
 #ifndef PT_PLOC_RADIUS
@@ -1083,15 +1334,15 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
     PT_HIP(ctx, sort_tmp.alloc(tmp_bytes));
     PT_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, tmp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int)n, 0, 63, st));
-    // Binary tree over the sorted references (node ids: internal 0..n-2, leaf j -> (n-1)+j).  Two candidates: agglomerative
-    // clustering and the plain Morton radix tree.  Clustering gives the better hierarchy for surfaces (architecture, terrain:
-    // 6 to 25 % lower cost); for unstructured clouds of small primitives (foliage) the radix tree comes out ahead (the large
-    // test scene: cost 67.0 against 67.8, 9 % more rays per second).  By default both are built and the one whose
-    // surface-area-optimal collapse is cheaper (c(root, 1) of k_collapse_dp) is kept; the radix tree adds about a fifth to
-    // the build time.  PT_BUILD_LBVH / PT_BUILD_CLUSTER build one of them only.
+    // Binary tree over the sorted references (node ids: internal 0..n-2, leaf j -> (n-1)+j): the Morton radix tree, improved
+    // by treelet restructuring passes (7 % more rays per second than agglomerative clustering without them on the
+    // architectural test scenes, 4 % on the large one, at a lower build time).  PT_BUILD_CLUSTER builds the clustered tree
+    // instead; with PT_BUILD_LBVH as well both are built and the one whose surface-area-optimal collapse is cheaper
+    // (c(root, 1) of k_collapse_dp) is kept.  PT_BUILD_NO_TREELET leaves the restructuring out.
     const bool greedy = (flags & PT_BUILD_GREEDY) != 0;
-    const bool want_radix = (flags & PT_BUILD_LBVH) || (!(flags & PT_BUILD_CLUSTER) && !greedy && n > 1);
-    const bool want_cluster = !(flags & PT_BUILD_LBVH);
+    const bool want_cluster = (flags & PT_BUILD_CLUSTER) != 0;
+    const bool want_radix = !want_cluster || ((flags & PT_BUILD_LBVH) && !greedy && n > 1);
+    const bool treelets = !(flags & PT_BUILD_NO_TREELET) && n > 1;
     uint32_t root_id = 0;
     DevBuf<uint2> children_r;                  // the radix tree when both are built
     DevBuf<float4> b2lo_r, b2hi_r;
@@ -1113,6 +1364,10 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         PT_HIP(ctx, hipMemsetAsync(parent.p, 0xFF, 2 * (size_t)n * sizeof(uint32_t), st));
         if (n > 1) k_karras<<<G, B, 0, st>>>((int)n, keys_sorted.p, ch, parent.p);
         k_refit<<<G, B, 0, st>>>((int)n, vals_sorted.p, src_lo, src_hi, ch, parent.p, flagsb.p, lo2, hi2);
+        for (int pass = 0; treelets && pass < PT_TREELET_PASSES; pass++) {
+            PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
+            k_treelet_up<<<(n + 63) / 64, 64, 0, st>>>((int)n, ch, parent.p, flagsb.p, lo2, hi2);
+        }
         if (n > 1 && !greedy) {
             PT_HIP(ctx, dpb->alloc(n));
             PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
@@ -1154,10 +1409,22 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
             if (++rounds > 4096) return set_error(ctx, PT_ERR_INVALID, "hierarchy build: clustering did not terminate");
         }
         const uint32_t cluster_root = n > 1 ? next_id - 1 : 0;   // the last node created is the root
+        if (treelets) {
+            k_parents<<<G, B, 0, st>>>((int)n, cluster_root, children.p, parent.p);
+            for (int pass = 0; pass < PT_TREELET_PASSES; pass++) {
+                PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
+                k_treelet_up<<<(n + 63) / 64, 64, 0, st>>>((int)n, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p);
+            }
+        }
         if (n > 1 && !greedy) {
             PT_HIP(ctx, dp.alloc(n));
-            for (auto& r : dp_rounds)
-                k_collapse_dp<<<(r.second + B - 1) / B, B, 0, st>>>(r.first, r.second, (int)n, cluster_root, children.p, b2lo.p, b2hi.p, dp.p);
+            if (treelets) {      // restructuring moved node numbers between depths: bottom-up by the parent pointers instead
+                PT_HIP(ctx, hipMemsetAsync(flagsb.p, 0, (size_t)n * sizeof(uint32_t), st));
+                k_collapse_dp_up<<<G, B, 0, st>>>((int)n, cluster_root, children.p, parent.p, flagsb.p, b2lo.p, b2hi.p, dp.p);
+            } else {
+                for (auto& r : dp_rounds)
+                    k_collapse_dp<<<(r.second + B - 1) / B, B, 0, st>>>(r.first, r.second, (int)n, cluster_root, children.p, b2lo.p, b2hi.p, dp.p);
+            }
         }
         bool keep_cluster = true;
         if (want_radix && n > 1 && !greedy) {

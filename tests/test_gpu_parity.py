@@ -231,15 +231,16 @@ def decode_child_boxes(node_words):
     return lo, hi, node_words[4:12]
 
 
-@pytest.mark.parametrize("flags", [2, 0])
+@pytest.mark.parametrize("flags", [2, 0, 18, 10])
 def test_hierarchy_is_well_formed(backend, cornell, flags):
     """flags 2: every triangle entered once.  flags 0: triangles with mostly empty boxes are entered once per cell they
-    pass through; such a reference's boxes bound its piece only, so containment is checked for the whole triangles."""
+    pass through; such a reference's boxes bound its piece only, so containment is checked for the whole triangles.
+    18: no treelet restructuring either; 10: the clustered tree."""
     backend.scene_upload(cornell)
     st = backend.build_accel(flags)
     nodes, tris = backend.debug_read_bvh()
     assert nodes.shape == (st.num_nodes, 32) and tris.shape == (st.num_references, 12)
-    assert st.num_references >= st.num_triangles and (flags == 0 or st.num_references == st.num_triangles)
+    assert st.num_references >= st.num_triangles and (not (flags & 2) or st.num_references == st.num_triangles)
     ids = tris[:, 3].astype(np.uint64) << np.uint64(32) | tris[:, 7].astype(np.uint64)
     uniq, inverse, counts = np.unique(ids, return_inverse=True, return_counts=True)
     assert len(uniq) == st.num_triangles         # every (submesh, prim) appears, once unless it was split
@@ -273,11 +274,11 @@ def test_hierarchy_is_well_formed(backend, cornell, flags):
     assert seen.all() and visited.all() and leaves == st.num_leaves
 
 
-@pytest.mark.parametrize("flags", [0, 1, 8, 4, 5])
+@pytest.mark.parametrize("flags", [0, 8, 9, 4, 12, 16, 24, 25])
 def test_both_builders_give_the_same_hits(backend, cornell, flags):
-    # 0 = the cheaper of the clustered tree and the Morton radix tree, 1 = radix tree only, 8 = clustering only (each with the
-    # surface-area-optimal collapse), 4 / 5 = clustering / radix tree with the greedy collapse: the hierarchy must not change
-    # any result
+    # 0 = Morton radix tree with treelet restructuring, 8 = clustering, 9 = the cheaper of the two (each with the
+    # surface-area-optimal collapse), 4 / 12 = radix tree / clustering with the greedy collapse, + 16 = without the treelet
+    # passes: the hierarchy must not change any result
     backend.scene_upload(cornell)
     backend.build_accel(flags)
     rng = np.random.default_rng(31 + flags)
@@ -288,7 +289,7 @@ def test_both_builders_give_the_same_hits(backend, cornell, flags):
 
 
 def test_optimal_collapse_fills_the_nodes(backend):
-    """The surface-area-optimal choice of each wide node's children against the greedy one on the same clustered tree:
+    """The surface-area-optimal choice of each wide node's children against the greedy one on the same binary tree:
     fewer and fuller nodes, lower cost, leaves of at most four triangles, the same hits."""
     sc = procedural.sponza_class(detail=0.2)
     backend.scene_upload(sc)
@@ -309,6 +310,29 @@ def test_optimal_collapse_fills_the_nodes(backend):
     assert np.array_equal(greedy[3], optimal[3])
     assert optimal[0] < 0.9 * greedy[0] and optimal[1] < 0.92 * greedy[1] and optimal[2] > greedy[2] + 1.5
     assert optimal[4][1] < 0.85 * greedy[4][1]           # triangle tests for the same rays
+
+
+def test_treelet_passes_lower_the_cost(backend):
+    """Treelet restructuring of the Morton radix tree: a cheaper hierarchy (surface-area cost, node visits of the same rays),
+    every reference still in exactly one leaf, the same hits; a clustered tree gains from the passes too."""
+    sc = procedural.sponza_class(detail=0.2)
+    backend.scene_upload(sc)
+    rng = np.random.default_rng(4)
+    rays = random_rays(rng, 20000, [-14, 0.3, -8], [14, 10.5, 8])
+    out = {}
+    for flags in (16, 0, 24, 8):
+        st = backend.build_accel(flags)
+        nodes, tris = backend.debug_read_bvh()
+        child = nodes[:, 4:12]
+        leaf = ((child >> 31) == 1) & (child != M32)
+        assert int((((child[leaf] >> 28) & 7) + 1).sum()) == st.num_references == len(tris)
+        first = np.sort(child[leaf] & 0x0FFFFFFF)
+        assert len(np.unique(first)) == len(first)
+        hits, counters = backend.debug_intersect(rays)
+        out[flags] = (st.sah_cost, hits, counters)
+    assert np.array_equal(out[0][1], out[16][1]) and np.array_equal(out[8][1], out[16][1])
+    assert out[0][0] < 0.9 * out[16][0] and out[0][2][0] < 0.95 * out[16][2][0]
+    assert out[8][0] < out[24][0]
 
 
 # ---- frames --------------------------------------------------------------------------------------------------
