@@ -117,7 +117,7 @@ int pt_scene_upload(pt_ctx* ctx, const pt_scene_desc* scene);
 #define PT_BUILD_DEFAULT 0u
 #define PT_BUILD_CLUSTER 8u    /* agglomerative clustering instead of the default tree (Morton radix tree + treelet restructuring) */
 #define PT_BUILD_LBVH 1u       /* with PT_BUILD_CLUSTER: build both trees and keep the one with the lower surface-area cost */
-#define PT_BUILD_NO_TREELET 16u /* no treelet restructuring passes (seven subtrees at a time, cheapest topology by summed box
+#define PT_BUILD_NO_TREELET 16u /* no treelet restructuring passes (eight subtrees at a time, cheapest topology by summed box
                                 * area) over the binary tree: PT_BUILD_NO_TREELET alone is the fastest build */
 #define PT_BUILD_GREEDY 4u     /* children of a wide node chosen greedily (largest box first) instead of by the surface-area-optimal
                                 * dynamic programme: kept for comparison */
