@@ -1059,3 +1059,19 @@ def test_degenerate_distributions_build_and_trace(backend, kind):
     want = o.intersect(rays, use_bvh=False)
     assert np.array_equal(got, want)
     assert (got[:, 3] != M32).sum() > 10 or kind == "line"
+
+
+def test_scenes_of_one_to_twenty_triangles(backend):
+    """Sizes around the treelet size (8 subtrees) and the leaf size (4): every builder variant equals the brute-force loop."""
+    rng = np.random.default_rng(5)
+    for n in range(1, 21):
+        tris = (rng.uniform(-1, 1, (n, 3, 3)) + rng.uniform(-4, 4, (n, 1, 3))).astype(np.float32)
+        sc = _soup(tris)
+        backend.scene_upload(sc)
+        rays = random_rays(rng, 400, [-5, -5, -5], [5, 5, 5])
+        want = oracle_lib.Oracle(sc).intersect(rays, use_bvh=False)
+        for flags in (0, 8, 16, 2):
+            st = backend.build_accel(flags)
+            assert st.num_triangles == n
+            got, _ = backend.debug_intersect(rays)
+            assert np.array_equal(got, want), (n, flags)
