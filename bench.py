@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--build-flags", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0, help="frames that share their launches (1..8; 0 = the timed frames in equal batches)")
     ap.add_argument("--detail", type=float, default=1.0, help="tessellation scale of the procedural scenes (1 = the benchmark scene)")
     ap.add_argument("--gltf", default=None, help="benchmark this glTF file (with its textures) instead of a built-in workload")
     ap.add_argument("--scale", type=float, default=1.0, help="layer transform of --gltf: uniform scale")
@@ -165,7 +166,7 @@ def main():
     # end on a short one (20 frames: 7 + 7 + 6 instead of 8 + 8 + 4)
     per_rank = args.steps
     nbatches = (per_rank + 7) // 8
-    b.set_batch(max(1, min(8, (per_rank + nbatches - 1) // nbatches)))
+    b.set_batch(args.batch if args.batch > 0 else max(1, min(8, (per_rank + nbatches - 1) // nbatches)))
 
     def barrier():
         b.sync()
