@@ -1068,21 +1068,30 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
             quantise_child(gr, lo, hi, pad, qlo, qhi);
             if (leafy(c)) {
                 nd.child[k] = PT_CHILD_LEAF | ((cnt - 1u) << 28) | tstart;
-                // write the subtree's triangles in depth-first order
-                uint32_t stack[16];
+                // write the subtree's triangles in the order of their (submesh, primitive): the triangle phase of the
+                // traversal resolves hits at equal distance inside a leaf by position
+                uint32_t stack[16], src[PT_LEAF_MAX];
+                unsigned long long ord[PT_LEAF_MAX];
                 int sp = 0;
-                uint32_t w = tstart;
+                uint32_t m = 0;
                 stack[sp++] = c;
                 while (sp) {
                     uint32_t id = stack[--sp];
                     if (is_leaf2(id)) {
-                        tris_out[w++] = tris_in[vals[id - (uint32_t)(n - 1)]];
+                        if (m < PT_LEAF_MAX) {
+                            const uint32_t t = vals[id - (uint32_t)(n - 1)];
+                            const unsigned long long key = ((unsigned long long)tris_in[t].submesh << 32) | tris_in[t].prim;
+                            uint32_t at = m++;
+                            while (at > 0 && ord[at - 1] > key) { ord[at] = ord[at - 1]; src[at] = src[at - 1]; at--; }
+                            ord[at] = key; src[at] = t;
+                        }
                     } else {
                         uint2 c2 = children[id];
                         stack[sp++] = c2.y;
                         stack[sp++] = c2.x;
                     }
                 }
+                for (uint32_t w = 0; w < m; w++) tris_out[tstart + w] = tris_in[src[w]];
                 atomicAdd(leaf_counter, 1u);
             } else {
                 uint32_t slot = atomicAdd(node_counter, 1u);

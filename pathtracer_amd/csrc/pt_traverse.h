@@ -54,6 +54,7 @@ namespace ptd {
 // (a lane picks the reference of a sorted child with one LDS read instead of a tree of selects over eight registers);
 // in the triangle phase the work list (one uint16 per triangle, 64 * PT_LEAF_MAX of them)
 #define PT_SCRATCH_WORDS (8 * 64)
+static_assert(64 * PT_LEAF_MAX * 2 + 64 * 8 <= PT_SCRATCH_WORDS * 4, "work list and result slots of the triangle phase share the scratch");
 
 struct HitRec {
     float t, u, v;
@@ -338,8 +339,8 @@ PT_DEV bool wins_tie(const TriRec* __restrict__ tris, uint32_t cand, uint32_t be
 
 // Triangle phase, run by the whole wave.  Every lane with a pending leaf owns 1..PT_LEAF_MAX work items (its
 // triangles); the items are numbered through the wave in lane order and item j is tested by lane j, with the
-// owner's ray fetched by lane permutes.  The owner then collects the distances of its items, keeps the closest
-// under the usual rules, and fetches that one's barycentric terms.  One call tests at most 64 items: lanes whose
+// owner's ray fetched by lane permutes.  Every hit is sent to its owner's LDS slot with a 64-bit minimum on (distance,
+// item); the owner compares the winner with its closest hit so far under the usual rules and fetches its barycentric terms.  One call tests at most 64 items: lanes whose
 // items do not fit keep their leaf pending for the next call (returns whether this lane's leaf was tested).
 // `owner` is this wave's LDS work list (the wave's scratch).  Must be called in wave-uniform control flow.
 template <bool STATS>
@@ -360,6 +361,8 @@ PT_DEV bool leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, 
     for (uint32_t k = 0; k < PT_LEAF_MAX; k++)
         if (k < cnt) owner[off + k] = (uint16_t)(lane | (k << 6));
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), 63 - __builtin_clzll(__ballot(mine) | 1ull));
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(owner + 64 * PT_LEAF_MAX);      // one per lane, after the work list
+    if (cnt != 0u) slot[lane] = ~0ull;
     __syncthreads();
     const uint32_t kpack = (uint32_t)s.rp.kx | ((uint32_t)s.rp.ky << 2) | ((uint32_t)s.rp.kz << 4);
     // ---- test item `lane`
@@ -381,17 +384,21 @@ PT_DEV bool leaf_phase(Trav& s, bool has_pend, const TriRec* __restrict__ tris, 
         float t, V, W, det;
         if (tri_test(wr, wo, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), w_tmin, t, V, W, det)) { wt = t; wV = V; wW = W; wdet = det; }
     }
-    // ---- owners collect
+    // ---- every hit goes to its owner's slot: the smallest (distance, item) wins.  Distances are positive, so their bit
+    // patterns order like the numbers; the items of a leaf follow each other in the order of their (submesh, primitive)
+    // (the builder writes leaves that way), so the item number settles hits at equal distance inside the leaf
+    if (work && wt < __builtin_inff()) atomicMin(&slot[src], ((unsigned long long)f2u(wt) << 32) | lane);
+    __syncthreads();
     uint32_t win = lane;
     bool won = false;
-#pragma unroll
-    for (uint32_t kk = 0; kk < PT_LEAF_MAX; kk++) {
-        const uint32_t jj = off + kk;
-        const float tk = lane_read(wt, jj & 63u);
-        if (kk < cnt && tk < s.tmax) {
+    if (cnt != 0u) {
+        const unsigned long long got = slot[lane];
+        const float tk = u2f((uint32_t)(got >> 32));
+        const uint32_t jj = (uint32_t)got & 63u;
+        if (got != ~0ull && tk < s.tmax) {
             bool take = tk < s.best.t;
-            if (tk == s.best.t && s.best.tri != 0xFFFFFFFFu) take = wins_tie(tris, first + kk, s.best.tri);
-            if (take) { s.best.t = tk; s.best.tri = first + kk; win = jj & 63u; won = true; }
+            if (tk == s.best.t && s.best.tri != 0xFFFFFFFFu) take = wins_tie(tris, first + (jj - off), s.best.tri);
+            if (take) { s.best.t = tk; s.best.tri = first + (jj - off); win = jj; won = true; }
         }
     }
     const float gV = lane_read(wV, win), gW = lane_read(wW, win), gdet = lane_read(wdet, win);

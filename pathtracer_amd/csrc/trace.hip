@@ -199,7 +199,7 @@ template <bool STATS, bool CUT>
 __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneView sc, ExtendArgs a, unsigned long long* stats, unsigned long long* wave_trace)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
-    __shared__ uint32_t scratch[PT_SCRATCH_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t scratch[PT_SCRATCH_WORDS];
     const uint32_t ls = blockIdx.x % a.nshards;
     const uint32_t n = a.counts[ls];
     const uint32_t base = (a.shard0 + ls) * a.shard_cap;
@@ -832,7 +832,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
                                                                 uint32_t* __restrict__ out, uint2* spill, uint32_t stack_entries, unsigned long long* stats)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
-    __shared__ uint32_t scratch[PT_SCRATCH_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t scratch[PT_SCRATCH_WORDS];
     uint32_t sn = 0, st = 0;
     trace_wave<true, false>(
         sc.nodes, sc.tris, sc.num_tris, n, cursor, stack + threadIdx.x, EXT_BLOCK,
