@@ -122,6 +122,19 @@ try:
             out["fabric_bytes_per_ray"] = (2.0 * tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / rays
         if "TCC_HIT_sum" in tot and tot["TCC_HIT_sum"] + tot.get("TCC_MISS_sum", 0.0) > 0:
             out["l2_hit_rate"] = tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"])
+        # GRBM_GUI_ACTIVE comes summed over the 8 XCDs; the _sum counters over the 256 per-CU units.  Counter passes run the
+        # kernels one at a time, so these are each launch alone on the chip
+        cu_cycles = 256.0 * tot["GRBM_GUI_ACTIVE"] / 8.0 if tot.get("GRBM_GUI_ACTIVE") else 0.0
+        if "TA_TA_BUSY_sum" in tot and cu_cycles:
+            out["ta_busy_frac"] = tot["TA_TA_BUSY_sum"] / cu_cycles
+        if "TCP_PENDING_STALL_CYCLES_sum" in tot and cu_cycles:
+            out["l1_pending_stall_frac"] = tot["TCP_PENDING_STALL_CYCLES_sum"] / cu_cycles     # the in-order L1 waiting on a line in flight
+        if "TA_FLAT_READ_WAVEFRONTS_sum" in tot:
+            out["vmem_read_insts_per_ray"] = tot["TA_FLAT_READ_WAVEFRONTS_sum"] / rays
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in tot and tot["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
+            out["l1_accesses_per_ray"] = tot["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays
+            if "TCP_TCC_READ_REQ_sum" in tot:
+                out["l1_read_miss_per_access"] = tot["TCP_TCC_READ_REQ_sum"] / tot["TCP_TOTAL_CACHE_ACCESSES_sum"]
         if "SQ_WAIT_ANY" in tot and tot.get("SQ_WAVE_CYCLES"):
             out["parked_share_of_wave_cycles"] = tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"]
         return out
