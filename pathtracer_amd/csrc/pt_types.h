@@ -33,7 +33,8 @@ struct alignas(128) Node8 {
 #define PT_MAX_CHAINS 16    // independent pipelines a frame can be split into (a divisor of PT_SHARDS)
 #endif
 
-// world-space triangle, 48 bytes, in leaf order: (v0, submesh) (v1, prim) (v2, 0)
+// world-space triangle, 48 bytes, in leaf order: (v0, submesh) (v1, prim) (v2, 0).  Inside a leaf the records are in
+// ascending (submesh, prim) order: the traversal's triangle phase settles hits at equal distance by position in the leaf
 struct alignas(16) TriRec {
     float v0x, v0y, v0z; uint32_t submesh;
     float v1x, v1y, v1z; uint32_t prim;

@@ -265,6 +265,7 @@ def test_hierarchy_is_well_formed(backend, cornell, flags):
                 first, cnt = ch & 0x0FFFFFFF, ((ch >> 28) & 7) + 1
                 assert cnt <= 4 and not seen[first:first + cnt].any()
                 seen[first:first + cnt] = True
+                assert (np.diff(ids[first:first + cnt].astype(np.int64)) >= 0).all()     # a leaf's records in (submesh, prim) order
                 leaves += 1
                 p = tv[first:first + cnt][whole[first:first + cnt]].reshape(-1, 3)
                 for (blo, bhi) in mine:               # every ancestor's decoded box contains the triangles
