@@ -37,7 +37,13 @@
 namespace ptd {
 
 static constexpr int EXT_BLOCK = 64;     // one wave per workgroup: its LDS stack is PT_STACK_LDS * 64 * 8 bytes
-static constexpr int SHADE_BLOCK = 256;
+// Workgroups of one wave: the shading launch shares the chip with the traversal launches of the other chains, whose waves
+// hold most wave slots; a single wave is placed as soon as one slot frees up, a workgroup of four waits for room for all
+// four on one CU (256 threads: 6 % fewer rays per second on the mid-sized scenes, 3.5 % on the large one)
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 64
+#endif
+static constexpr int SHADE_BLOCK = PT_SHADE_BLOCK;
 static constexpr uint32_t MISS = 0xFFFFFFFFu;
 
 struct Queues {
@@ -684,10 +690,11 @@ int launch_trace(pt_ctx* ctx)
     const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? (ctx->accel_stats.sah_cost >= 20.0f ? 64u : 48u) : 40u);
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
-    static const uint32_t shade_override = getenv("PT_SHADE_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("PT_SHADE_BLOCKS_PER_CU")) : 0u;
-    // shading: 4 workgroups of 256 per CU over all chains (measured: 8 is 1.5-3.5 % slower on four scenes, 2 is 1-5 % slower):
-    // the launch waits on gathers, and waves it holds beyond that only take registers from the traversal
-    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, (uint32_t)ctx->num_cus * (shade_override ? shade_override : 4u), nframes);
+    static const uint32_t shade_override = getenv("PT_SHADE_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_SHADE_WAVES_PER_CU")) : 0u;
+    // shading: 16 waves per CU over all chains (flat from 16 to 48; with workgroups of four waves twice as many were 1.5-3.5 %
+    // slower and half as many 1-5 %): the launch waits on gathers, and waves it holds beyond that only take registers from the
+    // traversal.  A shallow scene, whose frame is mostly shading, takes 32 (the Cornell box: +8 %)
+    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, (uint32_t)ctx->num_cus * (shade_override ? shade_override : (ctx->accel_stats.sah_cost >= 20.0f ? 16u : 32u)) * 64u / SHADE_BLOCK, nframes);
     // a chain's share of the spill area and of the suspension records is laid out for a full batch, so that a
     // short batch launched while a full one is still running stays inside its own chain's share
     const uint32_t ext_blocks_max = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, PT_MAX_BATCH);
