@@ -454,12 +454,13 @@ __global__ void __launch_bounds__(256) k_accumulate(TraceParams P, Queues q)
     }
 }
 
-// Shading is compiled for 96 registers (5 waves per SIMD): a traversal wave takes 104 of a SIMD's 512 and four of them
-// leave 96, so a shading wave of this size runs beside four traversal waves where the unconstrained kernel (140 registers)
-// displaced one of them.  The price is 43 spilled words per lane; measured +1 ... +4.5 % of the frame on four scenes, while a
-// limit of 128 registers (room beside three traversal waves only, like 140) measured -1 ... -3 %.
+// Shading is compiled without a register cap (140 registers, nothing spilled).  With workgroups of four waves a cap of 96
+// registers paid (a wave of that size fits beside four traversal waves of 104; +1 ... +4.5 % in spite of 43 spilled words per
+// lane); with workgroups of one wave the uncapped kernel is ahead (+3.5 % on the mid-sized scenes, +0.5 % on the large one,
+// +13 % on the Cornell box): the spills were a third of the kernel's loads and most of its stores, and the vector-memory path
+// is nearly as busy as the vector ALUs.  128 registers: +1.5 %; 84 (6 waves per SIMD): -8 %.
 #ifndef PT_SHADE_WAVES_PER_SIMD
-#define PT_SHADE_WAVES_PER_SIMD 5
+#define PT_SHADE_WAVES_PER_SIMD 3
 #endif
 __global__ void __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES_PER_SIMD, PT_SHADE_WAVES_PER_SIMD))) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
 {
@@ -691,10 +692,10 @@ int launch_trace(pt_ctx* ctx)
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
     static const uint32_t shade_override = getenv("PT_SHADE_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_SHADE_WAVES_PER_CU")) : 0u;
-    // shading: 16 waves per CU over all chains (flat from 16 to 48; with workgroups of four waves twice as many were 1.5-3.5 %
+    // shading: 24 waves per CU over all chains (flat from 12 to 32; with workgroups of four waves twice as many were 1.5-3.5 %
     // slower and half as many 1-5 %): the launch waits on gathers, and waves it holds beyond that only take registers from the
-    // traversal.  A shallow scene, whose frame is mostly shading, takes 32 (the Cornell box: +8 %)
-    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, (uint32_t)ctx->num_cus * (shade_override ? shade_override : (ctx->accel_stats.sah_cost >= 20.0f ? 16u : 32u)) * 64u / SHADE_BLOCK, nframes);
+    // traversal.  A shallow scene, whose frame is mostly shading, takes 32 (the Cornell box: +3 % over 16)
+    uint32_t sh_blocks = chain_grid(SHADE_BLOCK, (uint32_t)ctx->num_cus * (shade_override ? shade_override : (ctx->accel_stats.sah_cost >= 20.0f ? 24u : 32u)) * 64u / SHADE_BLOCK, nframes);
     // a chain's share of the spill area and of the suspension records is laid out for a full batch, so that a
     // short batch launched while a full one is still running stays inside its own chain's share
     const uint32_t ext_blocks_max = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, PT_MAX_BATCH);
