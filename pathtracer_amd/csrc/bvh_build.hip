@@ -25,6 +25,8 @@
 #include "pt_traverse.h"
 #include "pt_math.h"
 #include <hipcub/hipcub.hpp>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -1466,6 +1468,12 @@ int build_accel(pt_ctx* ctx, uint32_t flags)
         }
     }
 
+    if (dp_p && n > 1 && getenv("PT_BUILD_STATS")) {      // the cost the collapse minimises, for comparisons with other builders
+        float c = 0.0f;
+        PT_HIP(ctx, hipMemcpyAsync(&c, &dp_p[root_id].c[0], sizeof(float), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        fprintf(stderr, "pathtracer_amd: hierarchy build: %u references, collapse cost c(root, 1) = %.3f\n", n, c);
+    }
     // collapse: counters[0] = nodes allocated, [1] = leaves, [2],[3] = frontier sizes (ping-pong)
     uint32_t init[4] = {1u, 0u, 0u, 0u};
     PT_HIP(ctx, hipMemcpyAsync(counters.p, init, sizeof(init), hipMemcpyHostToDevice, st));
