@@ -34,9 +34,6 @@ namespace ptd {
 
 static constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-#ifndef PT_FILL_SLOTS
-#define PT_FILL_SLOTS 0
-#endif
 
 __device__ __forceinline__ int f2ord(float f)
 {
@@ -1029,23 +1026,6 @@ __global__ void k_collapse(uint32_t nitems, const CollapseItem* __restrict__ in,
             cand[bestk] = c2.x;
             cand[nc++] = c2.y;
         }
-#if PT_FILL_SLOTS
-        // slots left over: split the largest leaves further.  A ray tests all eight slots of a node anyway, and
-        // smaller leaves mean fewer triangle tests behind the boxes it enters.
-        while (nc < 8) {
-            int bestk = -1;
-            float besta = -1.0f;
-            for (int k = 0; k < nc; k++) {
-                if (is_leaf2(cand[k]) || count_of(cand[k]) > PT_LEAF_MAX) continue;
-                float a = box_area(b2lo[cand[k]], b2hi[cand[k]]) * (float)count_of(cand[k]);
-                if (a > besta) { besta = a; bestk = k; }
-            }
-            if (bestk < 0) break;
-            uint2 c2 = children[cand[bestk]];
-            cand[bestk] = c2.x;
-            cand[nc++] = c2.y;
-        }
-#endif
     }
     NodeGrid gr;
     {

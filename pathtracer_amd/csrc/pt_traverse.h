@@ -271,24 +271,6 @@ PT_DEV bool node_step(Trav& s, const Node8* __restrict__ nodes, uint2* lds_stack
     PT_CE(2, 4) PT_CE(3, 5)
     PT_CE(1, 2) PT_CE(3, 4) PT_CE(5, 6)
 #undef PT_CE
-#ifdef PT_DUMMY_VALU
-    {   // experiment: extra independent VALU work per node step
-        uint32_t d0 = key[0], d1 = key[1];
-#pragma unroll
-        for (int k = 0; k < PT_DUMMY_VALU / 2; k++) {
-            asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(d0) : "v"(key[2]), "v"(key[3]));
-            asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(d1) : "v"(key[4]), "v"(key[5]));
-        }
-        asm volatile("" :: "v"(d0), "v"(d1));
-    }
-#endif
-#ifdef PT_DUMMY_LDS
-#pragma unroll
-    for (int k = 0; k < PT_DUMMY_LDS; k++) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"((uint32_t)(size_t)child_row), "v"(key[k & 7]), "n"((k & 7) * 256) : "memory");
-#endif
-#ifdef PT_DUMMY_SLEEP
-    __builtin_amdgcn_s_sleep(PT_DUMMY_SLEEP);
-#endif
     // farthest first, so the nearest is popped (or followed) first
     stack_reserve(s, lds_stack, stride, ovf, 7);
 #pragma unroll
