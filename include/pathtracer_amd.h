@@ -107,6 +107,7 @@ typedef struct pt_ctx pt_ctx;
 int pt_create(int device_ordinal, pt_ctx** out);
 void pt_destroy(pt_ctx* ctx);
 const char* pt_last_error(pt_ctx* ctx);   /* ctx may be NULL: last error of pt_create */
+const char* pt_last_warning(pt_ctx* ctx); /* advice left by the last pt_set_chains; empty when there is none */
 void pt_default_params(pt_params* out);
 
 /* Mesh vertex/index buffers, submesh table, material buffer, textures, radiance map:
@@ -186,14 +187,18 @@ int pt_ray_count(pt_ctx* ctx, uint64_t* rays);
 /* A frame is traced as `chains` (1, 2, 4, 8 or 16) independent pipelines, each with a share of the
  * pixel tiles and a HIP stream of its own, so that the tail of one pipeline's traversal launch
  * overlaps the others' work; images do not depend on the setting.  Chains overlap only if HIP has
- * a hardware queue for each: the default is 4, or 8 / 16 when GPU_MAX_HW_QUEUES >= 8 / >= 16 is in
- * the environment (HIP reads it when its runtime starts; 16 is the measured optimum, more queues
- * than chains cost throughput).  The library sets GPU_MAX_HW_QUEUES=16 itself when it is loaded with
- * the variable unset, which takes effect if no HIP call has been made yet.  After a successful
- * pt_set_chains, pt_last_error holds a warning text when chains exceeds the queues the variable
- * allows, else an empty string.  No counterpart in the reference, whose scheduling is the Vulkan
+ * a hardware queue for each.  HIP gives a process 4 unless GPU_MAX_HW_QUEUES says otherwise, and reads the
+ * variable when its runtime starts (16 is the measured optimum, more queues than chains cost throughput).
+ * A value the caller put in the environment is taken at its word: the default number of chains is then
+ * 4, 8 or 16 for < 8, >= 8, >= 16.  With the variable unset the library sets it to 16 when it is loaded,
+ * which only helps if no HIP call has been made yet in the process; pt_create therefore measures how many
+ * of its streams really run side by side (a millisecond) and chooses the default from that.  After a
+ * successful pt_set_chains, pt_last_warning holds a text when chains exceeds those queues, else an empty
+ * string; pt_last_error is left alone.  No counterpart in the reference, whose scheduling is the Vulkan
  * driver's. */
 int pt_set_chains(pt_ctx* ctx, uint32_t chains);
+/* hardware queues the context found for its streams (the caller's GPU_MAX_HW_QUEUES, else measured: 4, 8 or 16) */
+uint32_t pt_hardware_queues(pt_ctx* ctx);
 /* Up to `frames` (1..8) consecutive pt_trace calls share their kernel launches: the paths of all
  * of them fill one set of ray queues, so a launch has that many times the rays to hide its tail
  * behind.  1 launches every frame at its pt_trace call (lowest latency for an interactive viewer

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
 
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_default_params", "pt_scene_upload", "pt_build_accel",
+    "pt_create", "pt_destroy", "pt_last_error", "pt_last_warning", "pt_hardware_queues", "pt_default_params", "pt_scene_upload", "pt_build_accel",
     "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
     "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
@@ -59,6 +59,10 @@ def load_library():
     lib.pt_destroy.restype = None
     lib.pt_last_error.argtypes = [vp]
     lib.pt_last_error.restype = C.c_char_p
+    lib.pt_last_warning.argtypes = [vp]
+    lib.pt_last_warning.restype = C.c_char_p
+    lib.pt_hardware_queues.argtypes = [vp]
+    lib.pt_hardware_queues.restype = C.c_uint32
     lib.pt_default_params.argtypes = [C.POINTER(Params)]
     lib.pt_default_params.restype = None
     lib.pt_scene_upload.argtypes = [vp, C.POINTER(SceneDesc)]
@@ -236,6 +240,12 @@ class Backend:
     def set_chains(self, chains):
         """Number of independent pipelines (1, 2, 4 or 8) a frame is split into; images do not depend on it."""
         self._check(self.lib.pt_set_chains(self.h, int(chains)))
+
+    def last_warning(self):
+        return self.lib.pt_last_warning(self.h).decode()
+
+    def hardware_queues(self):
+        return int(self.lib.pt_hardware_queues(self.h))
 
     def set_batch(self, frames):
         """Consecutive trace() calls (1..8) that share their kernel launches; images do not depend on it."""

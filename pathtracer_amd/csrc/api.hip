@@ -14,11 +14,49 @@ static thread_local std::string g_create_error;
 // A frame runs as up to 16 chains, each on a HIP stream that needs a hardware queue of its own; HIP gives a process 4
 // unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable when its runtime starts (its first API call).  When
 // the library is loaded before that (linked into the application, or dlopen'ed before any HIP call) and the variable
-// is unset, it asks for 16 here, so that a host application gets the full rate without a launcher script.
+// is unset, it asks for 16 here, so that a host application gets the full rate without a launcher script.  Whether the
+// request took effect is not known at this point (the runtime may have started earlier, e.g. a host that used torch.cuda
+// or another HIP library first): pt_create then measures how many streams really run side by side (probe_hw_queues)
+// instead of reading the variable back.  setenv is not thread safe against getenv in other threads: load the library
+// before starting threads, or set the variable in the launcher.
 static bool g_asked_for_queues = false;
 __attribute__((constructor)) static void ask_for_hardware_queues()
 {
     if (!getenv("GPU_MAX_HW_QUEUES")) g_asked_for_queues = setenv("GPU_MAX_HW_QUEUES", "16", 0) == 0;
+}
+
+// holds a wave for `ticks` of the 100 MHz wall clock; every wave leaves after that time whatever happens
+__global__ void k_hold(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+// How many of the context's streams run side by side: one single-wave kernel that holds for 0.4 ms on each of the 16
+// streams.  With a hardware queue per stream all of them overlap and the whole takes 0.4 ms; streams that share a queue
+// run one after the other (8 queues: 0.8 ms, 4 queues: 1.6 ms).  Costs one to two milliseconds, once per context.
+static uint32_t probe_hw_queues(pt_ctx* ctx)
+{
+    const float hold_ms = 0.4f;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return 4u; }
+    for (uint32_t c = 0; c < PT_MAX_CHAINS; c++) k_hold<<<1, 64, 0, ctx->chain_stream[c]>>>(1000ull);     // first launches pay for code upload
+    for (uint32_t c = 0; c < PT_MAX_CHAINS; c++) (void)hipStreamSynchronize(ctx->chain_stream[c]);
+    (void)hipEventRecord(e0, ctx->stream);
+    for (uint32_t c = 1; c < PT_MAX_CHAINS; c++) (void)hipStreamWaitEvent(ctx->chain_stream[c], e0, 0);
+    for (uint32_t c = 0; c < PT_MAX_CHAINS; c++) k_hold<<<1, 64, 0, ctx->chain_stream[c]>>>((unsigned long long)(hold_ms * 1e5f));
+    for (uint32_t c = 1; c < PT_MAX_CHAINS; c++) {
+        (void)hipEventRecord(ctx->chain_done[c], ctx->chain_stream[c]);
+        (void)hipStreamWaitEvent(ctx->stream, ctx->chain_done[c], 0);
+    }
+    (void)hipEventRecord(e1, ctx->stream);
+    float ms = 1e9f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e9f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    const float rounds = ms / hold_ms;            // streams per hardware queue
+    return rounds < 1.5f ? 16u : (rounds < 3.0f ? 8u : 4u);
 }
 
 int set_error(pt_ctx* ctx, int code, const std::string& msg)
@@ -206,10 +244,20 @@ int pt_create(int device_ordinal, pt_ctx** out)
         es = hipStreamCreateWithFlags(&ctx->chain_stream[c], hipStreamNonBlocking);
         if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming);
     }
-    // Chains only overlap when each has a hardware queue of its own: HIP gives a process 4 unless
-    // GPU_MAX_HW_QUEUES (read when the runtime starts) says otherwise.
-    uint32_t hwq = 4;
-    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = (uint32_t)atoi(e);
+    // Chains only overlap when each has a hardware queue of its own: HIP gives a process 4 unless GPU_MAX_HW_QUEUES
+    // (read when the runtime starts) says otherwise.  A value the caller set is taken at its word; when the library set
+    // it itself (or nobody did) the overlap is measured
+    if (es == hipSuccess) {
+        const char* e = getenv("GPU_MAX_HW_QUEUES");
+        if (e && !g_asked_for_queues) {
+            ctx->hw_queues = (uint32_t)atoi(e);
+            ctx->hw_queues_source = "GPU_MAX_HW_QUEUES=" + std::string(e) + " in the environment";
+        } else {
+            ctx->hw_queues = probe_hw_queues(ctx);
+            ctx->hw_queues_source = "measured: " + std::to_string(ctx->hw_queues) + " of 16 streams ran side by side";
+        }
+    }
+    const uint32_t hwq = ctx->hw_queues;
     ctx->chains = hwq >= 16 ? 16u : (hwq >= 8 ? 8u : 4u);
     if (const char* e = getenv("PT_DEFER")) { int v = atoi(e); ctx->defer_rounds = v < 0 ? 0u : (v > 8 ? 8u : (uint32_t)v); }
     if (const char* e = getenv("PT_CHAINS")) {
@@ -260,6 +308,8 @@ void pt_destroy(pt_ctx* ctx)
 }
 
 const char* pt_last_error(pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+const char* pt_last_warning(pt_ctx* ctx) { return ctx ? ctx->warning.c_str() : ""; }
+uint32_t pt_hardware_queues(pt_ctx* ctx) { return ctx ? ctx->hw_queues : 0u; }
 
 void pt_default_params(pt_params* p)
 {
@@ -483,10 +533,8 @@ int pt_set_chains(pt_ctx* ctx, uint32_t chains)
     ctx->chains = chains;
     ctx->main_dirty = true;
     // not an error, but worth telling: chains that share a hardware queue run one after the other
-    uint32_t hwq = 4;
-    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = (uint32_t)atoi(e);
-    ctx->error = chains > hwq ? "warning: " + std::to_string(chains) + " chains but GPU_MAX_HW_QUEUES allows " + std::to_string(hwq) +
-                                " hardware queues; set GPU_MAX_HW_QUEUES >= chains before the HIP runtime starts" : std::string();
+    ctx->warning = chains > ctx->hw_queues ? "warning: " + std::to_string(chains) + " chains but the process has " + std::to_string(ctx->hw_queues) +
+                                               " hardware queues (" + ctx->hw_queues_source + "); set GPU_MAX_HW_QUEUES >= chains before the HIP runtime starts" : std::string();
     return PT_OK;
 }
 

@@ -22,6 +22,9 @@ struct pt_ctx {
     int num_cus = 0;
     hipStream_t stream = nullptr;            // main stream = stream of chain 0
     std::string error;
+    std::string warning;                     // advice that is not an error (pt_last_warning)
+    uint32_t hw_queues = 4;                  // hardware queues the process has: from the caller's GPU_MAX_HW_QUEUES, else measured
+    std::string hw_queues_source;
 
     // A frame is traced as `chains` independent pipelines, each owning PT_SHARDS / chains ray-queue shards (and the
     // pixel tiles that map to them) and running raygen -> (extend -> shade)* on its own stream.  The long tail of

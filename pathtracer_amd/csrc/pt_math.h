@@ -21,6 +21,9 @@
 #include <stdint.h>
 
 #define PT_DEV __device__ __forceinline__
+#define PT_PI 3.14159265358979323f
+#define PT_INV_PI 0.31830988618379067f
+#define PT_TWO_PI 6.28318530717958648f
 
 namespace ptd {
 
@@ -180,33 +183,11 @@ PT_DEV float round_to_half(float f)
     return u2f(sign | base);
 }
 
-// ---- 3-vectors ---------------------------------------------------------------
-struct v3 { float x, y, z; };
-PT_DEV v3 V3(float x, float y, float z) { return v3{x, y, z}; }
-PT_DEV v3 V3(float s) { return v3{s, s, s}; }
-PT_DEV v3 operator+(v3 a, v3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-PT_DEV v3 operator-(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-PT_DEV v3 operator*(v3 a, v3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-PT_DEV v3 operator*(v3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-PT_DEV v3 operator*(float s, v3 a) { return {s * a.x, s * a.y, s * a.z}; }
-PT_DEV v3 operator/(v3 a, float s) { return {fdiv(a.x, s), fdiv(a.y, s), fdiv(a.z, s)}; }
-PT_DEV v3 operator-(v3 a) { return {-a.x, -a.y, -a.z}; }
-PT_DEV v3 operator-(float s, v3 a) { return {s - a.x, s - a.y, s - a.z}; }
-PT_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-PT_DEV v3 cross(v3 a, v3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
-PT_DEV float inversesqrt(float x) { return fdiv(1.0f, fsqrt(x)); }
-PT_DEV v3 normalize(v3 v) { return v * inversesqrt(dot(v, v)); }
-PT_DEV float mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
-PT_DEV v3 mix(v3 a, v3 b, float t) { return a * (1.0f - t) + b * t; }
-PT_DEV v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
-PT_DEV v3 refract(v3 I, v3 N, float eta)
-{
-    float d = dot(N, I);
-    float k = 1.0f - eta * eta * (1.0f - d * d);
-    if (k < 0.0f) return V3(0.0f);
-    return I * eta - N * (eta * d + fsqrt(k));
-}
-PT_DEV float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+// ---- 3-vectors: v3, its operators, dot, cross, normalize, mix, reflect, refract.  The text is included a second time inside
+// namespace ptd::fast (pt_fast.h), where fdiv, fsqrt and inversesqrt are the single-instruction approximations
+#define PT_INVERSESQRT(x) fdiv(1.0f, fsqrt(x))
+#include "pt_vec.inc"
+#undef PT_INVERSESQRT
 
 // ---- RNG (PathTracer/assets/shaders/RayTracing/Globals.h:54-64) ----------------
 PT_DEV uint32_t pcg_hash(uint32_t& seed)

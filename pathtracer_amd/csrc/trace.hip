@@ -28,7 +28,7 @@
 // append counters are PT_SHARDS different words instead of one (a single word serialises at about
 // 90 atomics per microsecond, which bounded the whole shade stage), and because workgroups b and
 // b + 8 share an XCD, a shard's rays, hits and path state are touched by one XCD's L2 only.
-#include "pt_bsdf.h"
+#include "pt_math.h"
 #include "pt_context.h"
 #include "pt_traverse.h"
 #include <cstdlib>
@@ -94,6 +94,15 @@ PT_DEV void camera_ray(const TraceParams& P, const FrameView& V, uint32_t x, uin
     v3 dir = mat_mul_dir(V.inv_view, tn.x, tn.y, tn.z, 0.0f, dw);
     o = V3(V.inv_view[12], V.inv_view[13], V.inv_view[14]);
     d = normalize(dir);
+}
+
+// Camera rays are always generated with the bit-exact arithmetic, whichever arithmetic shades (primary hits then do not
+// depend on the precision mode); plain floats, because each arithmetic namespace has a vector type of its own
+PT_DEV void camera_ray_exact(const TraceParams& P, const FrameView& V, uint32_t x, uint32_t y, uint32_t sample, uint32_t& seed, float* od)
+{
+    v3 o, d;
+    camera_ray(P, V, x, y, sample, seed, o, d);
+    od[0] = o.x; od[1] = o.y; od[2] = o.z; od[3] = d.x; od[4] = d.y; od[5] = d.z;
 }
 
 // slot -> pixel: 8x8 pixel tiles, one tile per wave, so a wave's primary rays are a compact bundle
@@ -299,126 +308,6 @@ PT_DEV int wrap_index(int i, int n, uint32_t mode)
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-// texture(sampler2D, uv): level 0, RGBA8 UNORM; bilinear + repeat unless the texture's flags say otherwise
-PT_DEV float4 sample_texture(const SceneView& sc, int tex, float u, float v)
-{
-    const uint32_t* tt = sc.tex_table + tex * 4;
-    uint32_t off = tt[0], w = tt[1], h = tt[2], flags = tt[3];
-    const uint32_t ws = flags & 3u, wt = (flags >> 2) & 3u;
-    const bool nearest = (flags & 16u) != 0;
-    const uint32_t* px = reinterpret_cast<const uint32_t*>(sc.tex_pool) + off;
-    float uu = wrap_coord(u, ws), vv = wrap_coord(v, wt);
-    float x = uu * (float)w, y = vv * (float)h;
-    if (!nearest) { x = x - 0.5f; y = y - 0.5f; }
-    float x0f = floorf(x), y0f = floorf(y);
-    float fx = nearest ? 0.0f : x - x0f, fy = nearest ? 0.0f : y - y0f;
-    int x0 = (int)x0f, y0 = (int)y0f;
-    int x1 = nearest ? x0 : x0 + 1, y1 = nearest ? y0 : y0 + 1;
-    x0 = wrap_index(x0, (int)w, ws); x1 = wrap_index(x1, (int)w, ws);
-    y0 = wrap_index(y0, (int)h, wt); y1 = wrap_index(y1, (int)h, wt);
-    uint32_t p00 = px[(size_t)y0 * w + x0], p10 = px[(size_t)y0 * w + x1];
-    uint32_t p01 = px[(size_t)y1 * w + x0], p11 = px[(size_t)y1 * w + x1];
-    float out[4];
-    for (int ch = 0; ch < 4; ch++) {
-        const float k = 1.0f / 255.0f;
-        float c00 = (float)((p00 >> (8 * ch)) & 255u) * k, c10 = (float)((p10 >> (8 * ch)) & 255u) * k;
-        float c01 = (float)((p01 >> (8 * ch)) & 255u) * k, c11 = (float)((p11 >> (8 * ch)) & 255u) * k;
-        out[ch] = mix(mix(c00, c10, fx), mix(c01, c11, fx), fy);
-    }
-    return make_float4(out[0], out[1], out[2], out[3]);
-}
-
-// texture(samplerCube, d).rgb: z wins ties, then y; bilinear inside the face, clamp to edge
-PT_DEV v3 sample_env(const SceneView& sc, v3 d)
-{
-    float ax = gabs(d.x), ay = gabs(d.y), az = gabs(d.z);
-    int face;
-    float s_c, t_c, ma;
-    if (az >= ax && az >= ay) {
-        ma = az;
-        if (d.z < 0.0f) { face = 5; s_c = -d.x; t_c = -d.y; } else { face = 4; s_c = d.x; t_c = -d.y; }
-    } else if (ay >= ax) {
-        ma = ay;
-        if (d.y < 0.0f) { face = 3; s_c = d.x; t_c = -d.z; } else { face = 2; s_c = d.x; t_c = d.z; }
-    } else {
-        ma = ax;
-        if (d.x < 0.0f) { face = 1; s_c = d.z; t_c = -d.y; } else { face = 0; s_c = -d.z; t_c = -d.y; }
-    }
-    float n = (float)sc.env_n;
-    float s = 0.5f * (fdiv(s_c, ma) + 1.0f), t = 0.5f * (fdiv(t_c, ma) + 1.0f);
-    float x = s * n - 0.5f, y = t * n - 0.5f;
-    float x0f = floorf(x), y0f = floorf(y);
-    float fx = x - x0f, fy = y - y0f;
-    if (!(x0f == x0f)) x0f = 0.0f;
-    if (!(y0f == y0f)) y0f = 0.0f;
-    int N = (int)sc.env_n;
-    float top = (float)(N - 1);
-    int x0 = x0f < 0.0f ? 0 : (x0f > top ? N - 1 : (int)x0f);
-    int x1 = (x0f + 1.0f) < 0.0f ? 0 : ((x0f + 1.0f) > top ? N - 1 : (int)(x0f + 1.0f));
-    int y0 = y0f < 0.0f ? 0 : (y0f > top ? N - 1 : (int)y0f);
-    int y1 = (y0f + 1.0f) < 0.0f ? 0 : ((y0f + 1.0f) > top ? N - 1 : (int)(y0f + 1.0f));
-    const float4* base = reinterpret_cast<const float4*>(sc.env) + (size_t)face * N * N;
-    float4 c00 = base[(size_t)y0 * N + x0], c10 = base[(size_t)y0 * N + x1];
-    float4 c01 = base[(size_t)y1 * N + x0], c11 = base[(size_t)y1 * N + x1];
-    return V3(mix(mix(c00.x, c10.x, fx), mix(c01.x, c11.x, fx), fy),
-              mix(mix(c00.y, c10.y, fx), mix(c01.y, c11.y, fx), fy),
-              mix(mix(c00.z, c10.z, fx), mix(c01.z, c11.z, fx), fy));
-}
-
-// ClosestHit.glsl:144-226: what the payload needs downstream
-PT_DEV void fetch_surface(const SceneView& sc, const ShadeTri& st, float hu, float hv, v3 rayDir,
-                          Surf& s, v3& emission, v3& worldNormal)
-{
-    const float* M = sc.materials + (size_t)st.material * 22;
-    const float* o2w = sc.xforms + st.submesh * 12;
-
-    float bary[3] = {1.0f - hu - hv, hu, hv};
-    float uvx = 0.0f, uvy = 0.0f;
-    v3 nrm = V3(0.0f);
-    for (int i = 0; i < 3; i++) {
-        uvx += st.uv[i][0] * bary[i];
-        uvy += st.uv[i][1] * bary[i];
-        nrm = nrm + V3(st.n[i][0], st.n[i][1], st.n[i][2]) * bary[i];
-    }
-    nrm = normalize(nrm);
-    // mat3(gl_ObjectToWorldEXT) * normal -- not the inverse transpose (ClosestHit.glsl:170)
-    worldNormal = normalize(V3(o2w[0] * nrm.x + o2w[1] * nrm.y + o2w[2] * nrm.z,
-                               o2w[4] * nrm.x + o2w[5] * nrm.y + o2w[6] * nrm.z,
-                               o2w[8] * nrm.x + o2w[9] * nrm.y + o2w[10] * nrm.z));
-    v3 view = normalize(-rayDir);
-
-    v3 albedoTex = V3(1.0f);
-    int albedoMap = (int)f2u(M[10]);
-    int mrMap = (int)f2u(M[11]);
-    if (albedoMap != -1) {
-        float4 t = sample_texture(sc, albedoMap, uvx, uvy);
-        albedoTex = V3(t.x, t.y, t.z);
-    }
-    float mrx = 1.0f, mry = 1.0f;
-    if (mrMap != -1) {
-        float4 t = sample_texture(sc, mrMap, uvx, uvy);
-        mrx = t.z;   // .bg: metallic = blue, roughness = green (ClosestHit.glsl:182)
-        mry = t.y;
-    }
-    s.albedo = V3(M[0], M[1], M[2]) * albedoTex;
-    s.roughness = M[4] * mry;
-    s.metallic = M[3] * mrx;
-    emission = V3(M[5], M[6], M[7]) * M[8];
-    float anisotropic = M[13];
-    s.subsurface = M[14];
-    s.specularTint = M[15];
-    s.sheen = M[16];
-    s.sheenTint = M[17];
-    s.clearcoat = M[18];
-    s.clearcoatRoughness = M[19];
-    s.specTrans = M[20];
-    s.ior = M[21];
-    float aspect = fsqrt(1.0f - anisotropic * 0.9f);
-    s.ax = gmax(0.001f, fdiv(s.roughness, aspect));
-    s.ay = gmax(0.001f, s.roughness * aspect);
-    s.eta = dot(view, worldNormal) < 0.0f ? fdiv(1.0f, s.ior) : s.ior;
-}
-
 // RayGen.glsl:347-372 for every pixel of the chain and every frame of the batch, in frame order: the finished colours
 // wait in q.partial, so that a pixel's frames are added in the order of the pt_trace calls whatever order they finished in
 __global__ void __launch_bounds__(256) k_accumulate(TraceParams P, Queues q)
@@ -454,117 +343,37 @@ __global__ void __launch_bounds__(256) k_accumulate(TraceParams P, Queues q)
     }
 }
 
-// Shading is compiled without a register cap (140 registers, nothing spilled).  With workgroups of four waves a cap of 96
-// registers paid (a wave of that size fits beside four traversal waves of 104; +1 ... +4.5 % in spite of 43 spilled words per
-// lane); with workgroups of one wave the uncapped kernel is ahead (+3.5 % on the mid-sized scenes, +0.5 % on the large one,
-// +13 % on the Cornell box): the spills were a third of the kernel's loads and most of its stores, and the vector-memory path
-// is nearly as busy as the vector ALUs.  128 registers: +1.5 %; 84 (6 waves per SIMD): -8 %.
-#ifndef PT_SHADE_WAVES_PER_SIMD
-#define PT_SHADE_WAVES_PER_SIMD 3
-#endif
-__global__ void __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES_PER_SIMD, PT_SHADE_WAVES_PER_SIMD))) k_shade(SceneView sc, TraceParams P, Queues q, uint32_t round)
+// texture(sampler2D, uv): level 0, RGBA8 UNORM; bilinear + repeat unless the texture's flags say otherwise
+PT_DEV float4 sample_texture(const SceneView& sc, int tex, float u, float v)
 {
-    const uint32_t ls = blockIdx.x % q.nshards, lb = blockIdx.x / q.nshards, nb = gridDim.x / q.nshards;
-    const uint32_t shard = q.shard0 + ls;
-    const uint32_t n = q.counts[round * q.nshards + ls];
-    const uint32_t npix = P.width * P.height;
-    for (uint32_t base = lb * SHADE_BLOCK; base < n; base += nb * SHADE_BLOCK) {
-        uint32_t slot = shard * q.shard_cap + base + threadIdx.x;
-        bool valid = base + threadIdx.x < n;
-        bool alive = false;
-        v3 o = V3(0.0f), d = V3(0.0f);
-        uint32_t pixel = 0;            // the path: frame slot * pixels + pixel
-        float lag_bits = 0.0f;
-        float4 outA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), outB = outA;
-        if (valid && f2u(q.hits[slot].w) == DEFERRED) valid = false;     // suspended: the traversal kernel has queued it for the next round
-        if (valid) {
-            float4 ro = q.rayO_in[slot], rd = q.rayD_in[slot], h = q.hits[slot];
-            lag_bits = u2f(f2u(rd.w) & RAY_LAG_MASK);     // the path stays as far behind as it is
-            pixel = f2u(ro.w);
-            o = V3(ro.x, ro.y, ro.z);
-            d = V3(rd.x, rd.y, rd.z);
-            float4 A = q.stA_in[slot], B = q.stB_in[slot];
-            v3 thr = V3(A.x, A.y, A.z), rad = V3(B.x, B.y, B.z);
-            uint32_t seed = f2u(A.w);
-            uint32_t bs = f2u(B.w);
-            uint32_t bounce = bs & 0xFFFFu, sample = bs >> 16;
-            uint32_t tri = f2u(h.w);
-            bool done = false;
-            if (tri == MISS) {
-                if (bounce == 0 && sample == 0 && pixel / npix + 1u == P.nframes) q.primary[pixel % npix] = make_uint2(MISS, MISS);
-                v3 sky = sample_env(sc, d) * P.sky_scale;            // RayGen.glsl:128-135
-                rad = rad + sky * thr;
-                done = true;
-            } else {
-                ShadeTri st;
-                {
-                    const uint4* rec = reinterpret_cast<const uint4*>(sc.shade_tris + tri);
-                    uint4* dst = reinterpret_cast<uint4*>(&st);
-                    for (int w = 0; w < 5; w++) dst[w] = rec[w];
-                }
-                if (bounce == 0 && sample == 0 && pixel / npix + 1u == P.nframes) q.primary[pixel % npix] = make_uint2(st.submesh, st.prim);
-                Surf s;
-                v3 emission, N;
-                const float det = q.hit_det[slot];
-                fetch_surface(sc, st, fdiv(h.y, det), fdiv(h.z, det), d, s, emission, N);
-                rad = rad + emission * thr;                           // RayGen.glsl:137
-                bool last_bounce = bounce + 1 >= P.max_bounces;
-                if (last_bounce && sample + 1 >= P.spp) {
-                    done = true;    // nothing after this point can reach the pixel: skip the BSDF
-                } else {
-                    v3 negD = -d;
-                    v3 ff = dot(negD, N) < 0.0f ? -N : N;             // RayGen.glsl:147
-                    v3 L;
-                    float pdf;
-                    v3 f = disney_sample(s, negD, ff, L, pdf, seed);
-                    if (pdf > 0.0f) thr = thr * (f / pdf);            // RayGen.glsl:149-152
-                    else done = true;
-                    if (!done) {
-                        v3 fhp = o + d * h.x;                         // RayGen.glsl:156-160
-                        d = L;
-                        o = fhp + d * P.eps;
-                        if (P.rr_depth > 0 && bounce >= P.rr_depth) { // RayGen.glsl:163-173
-                            float qq = gmin(gmax(thr.x, gmax(thr.y, thr.z)) + 0.001f, 0.95f);
-                            if (random_value(seed) > qq) done = true;
-                            else thr = thr / qq;
-                        }
-                    }
-                    if (last_bounce) done = true;
-                    bounce++;
-                }
-            }
-            if (done) {
-                v3 color = sample > 0 ? V3(q.stC[pixel].x, q.stC[pixel].y, q.stC[pixel].z) : V3(0.0f);
-                color = color + rad;                                  // RayGen.glsl:344
-                sample++;
-                if (sample < P.spp) {
-                    q.stC[pixel] = make_float4(color.x, color.y, color.z, 0.0f);
-                    uint32_t px = pixel % npix;
-                    camera_ray(P, q.views[pixel / npix], px % P.width, px / P.width, sample, seed, o, d);
-                    thr = V3(1.0f);
-                    rad = V3(0.0f);
-                    bounce = 0;
-                    alive = true;
-                } else {
-                    q.partial[pixel] = make_float4(color.x, color.y, color.z, 0.0f);
-                }
-            } else {
-                alive = true;
-            }
-            if (alive) {
-                outA = make_float4(thr.x, thr.y, thr.z, u2f(seed));
-                outB = make_float4(rad.x, rad.y, rad.z, u2f(bounce | (sample << 16)));
-            }
-        }
-        uint32_t out = shard * q.shard_cap + wave_append(alive, &q.counts[(round + 1) * q.nshards + ls]);
-        if (alive) {
-            q.stA_out[out] = outA;
-            q.stB_out[out] = outB;
-            q.rayO_out[out] = make_float4(o.x, o.y, o.z, u2f(pixel));
-            q.rayD_out[out] = make_float4(d.x, d.y, d.z, lag_bits);
-        }
+    const uint32_t* tt = sc.tex_table + tex * 4;
+    uint32_t off = tt[0], w = tt[1], h = tt[2], flags = tt[3];
+    const uint32_t ws = flags & 3u, wt = (flags >> 2) & 3u;
+    const bool nearest = (flags & 16u) != 0;
+    const uint32_t* px = reinterpret_cast<const uint32_t*>(sc.tex_pool) + off;
+    float uu = wrap_coord(u, ws), vv = wrap_coord(v, wt);
+    float x = uu * (float)w, y = vv * (float)h;
+    if (!nearest) { x = x - 0.5f; y = y - 0.5f; }
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = nearest ? 0.0f : x - x0f, fy = nearest ? 0.0f : y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    int x1 = nearest ? x0 : x0 + 1, y1 = nearest ? y0 : y0 + 1;
+    x0 = wrap_index(x0, (int)w, ws); x1 = wrap_index(x1, (int)w, ws);
+    y0 = wrap_index(y0, (int)h, wt); y1 = wrap_index(y1, (int)h, wt);
+    uint32_t p00 = px[(size_t)y0 * w + x0], p10 = px[(size_t)y0 * w + x1];
+    uint32_t p01 = px[(size_t)y1 * w + x0], p11 = px[(size_t)y1 * w + x1];
+    float out[4];
+    for (int ch = 0; ch < 4; ch++) {
+        const float k = 1.0f / 255.0f;
+        float c00 = (float)((p00 >> (8 * ch)) & 255u) * k, c10 = (float)((p10 >> (8 * ch)) & 255u) * k;
+        float c01 = (float)((p01 >> (8 * ch)) & 255u) * k, c11 = (float)((p11 >> (8 * ch)) & 255u) * k;
+        out[ch] = mix(mix(c00, c10, fx), mix(c01, c11, fx), fy);
     }
+    return make_float4(out[0], out[1], out[2], out[3]);
 }
+
+#include "pt_shade.inc"      // sample_env, fetch_surface, k_shade: bit-exact arithmetic
+#include "pt_fast.h"         // the same text again as ptd::fast::k_shade with the hardware's approximations
 
 __global__ void k_finish(const uint32_t* counts, uint32_t entries, const uint32_t* deferred, unsigned long long* total)
 {

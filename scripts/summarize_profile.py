@@ -3,8 +3,7 @@
 usage: python scripts/summarize_profile.py gpurun_out/prof_r01 r01 [commit]
 writes profiles/<tag>_kernel_stats.md, profiles/<tag>_pmc.json, profiles/extend_traffic.json
 (the HBM bytes per k_extend launch that bench.py reports as roofline.traffic) and
-profiles/counters_per_ray.json (counters_per_ray_<workload>.json for another workload: BENCH_ARGS="--workload ..." to
-profile.sh and a tag like r02_bistro): vector instructions, vector-pipe busy cycles, fabric bytes, L2 hit rate and
+profiles/counters_per_ray_<workload>.json (BENCH_ARGS="--workload ..." to profile.sh selects the workload): vector instructions, vector-pipe busy cycles, fabric bytes, L2 hit rate and
 parked share of k_extend and k_shade per ray segment, which bench.py scales by the rays of its own run.
 """
 import glob
@@ -16,6 +15,8 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import csrc_sha16  # noqa: E402  (hash of the kernel sources the counters belong to)
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
@@ -27,7 +28,7 @@ def short(name):
 
 db = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
 rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
-lines = ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 16 --warmup 2 --cpu-seconds 0` (%s)" % tag, "",
+lines = ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 16 --warmup 2 --cpu-seconds 0 --others 0` (%s)" % tag, "",
          "| kernel | calls | total us | average us | % |", "|---|---|---|---|---|"]
 agg = {}
 for name, calls, total, avg, pct in rows:
@@ -82,7 +83,7 @@ for path in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_results.db"))):
 # the production traversal kernel: k_extend<false, true> (rounds that may defer rays); the last round of a frame
 # runs k_extend<false, false> on a nearly empty queue
 ext = pmc.get("ptd::k_extend<false, true>", {})
-summary = {"source": "rocprofv3 --pmc, one pass per counter group, bench.py --steps 16 --warmup 2 --cpu-seconds 0", "per_kernel": pmc}
+summary = {"source": "rocprofv3 --pmc, one pass per counter group, bench.py --steps 16 --warmup 2 --cpu-seconds 0 --others 0", "per_kernel": pmc}
 if "FETCH_SIZE" in ext:
     raw_kb = ext["FETCH_SIZE"]["avg"]
     wr_kb = ext.get("WRITE_SIZE", {}).get("avg", 0.0)
@@ -141,13 +142,13 @@ try:
 
     per = {"source": "rocprofv3 --pmc passes of scripts/profile.sh (FETCH_SIZE doubled per the gfx950 rule for 16-byte-per-lane reads: an "
                      "estimate for per-lane node gathers), summed over all launches of the kernel and divided by the ray segments they traced",
-           "commit": sys.argv[3] if len(sys.argv) > 3 else None, "tag": tag,
+           "commit": sys.argv[3] if len(sys.argv) > 3 else None, "csrc_sha16": csrc_sha16(), "tag": tag,
            "workload": bench["config"]["workload"], "rays_per_frame": rays_per_frame,
            "k_extend": per_ray(["ptd::k_extend<false, true>", "ptd::k_extend<false, false>"], plain_frames),
-           "k_shade": per_ray(["ptd::k_shade"], all_frames)}
+           "k_shade": per_ray([k for k in pmc if "k_shade" in k], all_frames)}
     summary["per_ray"] = per
     wl = bench["config"]["workload"].split(",")[0]
-    json.dump(per, open(os.path.join(out_dir, "counters_per_ray.json" if wl == "sponza_class" else "counters_per_ray_%s.json" % wl), "w"), indent=1)
+    json.dump(per, open(os.path.join(out_dir, "counters_per_ray_%s.json" % wl), "w"), indent=1)
 except (OSError, IndexError, KeyError, ValueError) as e:
     print("no per-ray summary:", e)
 json.dump(summary, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
