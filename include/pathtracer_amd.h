@@ -23,6 +23,7 @@ extern "C" {
 #define PT_ERR_NO_DEVICE 3    /* no gfx950 device, or ordinal out of range */
 #define PT_ERR_BVH_DEPTH 4    /* built hierarchy deeper than the traversal stack */
 #define PT_ERR_TOO_LARGE 5    /* size beyond a documented limit */
+#define PT_ERR_TRAVERSAL 6    /* a traversal wave reached its iteration bound: results since the last synchronisation are not valid */
 
 /* binding 9: sampler2D u_Textures[] (ClosestHit.glsl:15).  RGBA8 UNORM texels,
  * row 0 first; sampled at level 0, bilinear with repeat unless flags say otherwise (the
@@ -138,6 +139,22 @@ int pt_bind_images(pt_ctx* ctx, void* device_image, void* device_accum);
  * column-major (glm).  Only the last two are read by the shaders. */
 int pt_set_camera(pt_ctx* ctx, const float* five_mat4);
 int pt_set_params(pt_ctx* ctx, const pt_params* params);
+/* Arithmetic of the shading stage (sky look-up, ClosestHit surface fetch, DisneySample / DisneyEval, throughput and the
+ * next ray: Miss.glsl, ClosestHit.glsl:144-226, Disney.glsl:150-359, RayGen.glsl:126-173).
+ * PT_PRECISION_EXACT (default): correctly rounded IEEE binary32 operations in one fixed order; frames equal the CPU
+ *   oracle's bit for bit.
+ * PT_PRECISION_FAST: the hardware's reciprocal, square root, reciprocal square root, sin / cos and log2 / exp2 instructions
+ *   (1 ulp each, 2^-18 absolute for sin / cos) and fused multiply-adds: what a GLSL compiler is allowed to do with the
+ *   reference's shaders.  Camera rays, ray / triangle intersection and accumulation stay bit-exact, so the primary
+ *   hit ids of a frame do not change; a BSDF evaluation differs from the bit-exact one by 2e-7 relative at the median and
+ *   by less than 5e-4 in 99.9 % of random evaluations (ill-conditioned inputs, e.g. next to total internal reflection,
+ *   up to 1e-2), and a converged image (1024 samples per pixel) stays within relRMSE 1e-3 of the CPU oracle's: measured
+ *   1.2e-4 (tests/test_gpu_precision.py).  A path whose lobe choice or next hit
+ *   flips on a last-bit difference continues elsewhere, as it would between two Vulkan drivers.
+ * Frames already queued keep the mode they were traced with. */
+#define PT_PRECISION_EXACT 0
+#define PT_PRECISION_FAST 1
+int pt_set_precision(pt_ctx* ctx, int mode);
 /* vkCmdTraceRaysKHR(width, height, 1) with SceneBuffer.FrameIndex = frame_index, binding 7
  * (RayTracingLayer.cpp:274-283, RayGen.glsl:312-373).  Asynchronous: the frame takes the camera
  * and parameters in force at the call and is queued; up to pt_set_batch consecutive frames are

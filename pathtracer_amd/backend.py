@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
 
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_last_warning", "pt_hardware_queues", "pt_default_params", "pt_scene_upload", "pt_build_accel",
-    "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_trace", "pt_sync",
+    "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_set_precision", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
     "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
     "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_wait_stream", "pt_device_image", "pt_device_accum",
@@ -72,6 +72,7 @@ def load_library():
     lib.pt_bind_images.argtypes = [vp, vp, vp]
     lib.pt_set_camera.argtypes = [vp, fp]
     lib.pt_set_params.argtypes = [vp, C.POINTER(Params)]
+    lib.pt_set_precision.argtypes = [vp, C.c_int]
     lib.pt_trace.argtypes = [vp, C.c_uint32]
     lib.pt_sync.argtypes = [vp]
     lib.pt_read_image.argtypes = [vp, fp]
@@ -171,6 +172,10 @@ class Backend:
 
     def set_params(self, params: Params):
         self._check(self.lib.pt_set_params(self.h, C.byref(params)))
+
+    def set_precision(self, mode):
+        """0 = bit-exact shading arithmetic (default), 1 = the hardware's approximate division / square root / sin / cos / log / exp."""
+        self._check(self.lib.pt_set_precision(self.h, int(mode)))
 
     # ---- rendering ------------------------------------------------------------------------
     def trace(self, frame_index):

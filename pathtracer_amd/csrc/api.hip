@@ -187,6 +187,15 @@ static int finish_timing(pt_ctx* ctx)
     return PT_OK;
 }
 
+int check_fault(pt_ctx* ctx)
+{
+    if (!ctx->h_fault || *(volatile uint32_t*)ctx->h_fault == 0u) return PT_OK;
+    *(volatile uint32_t*)ctx->h_fault = 0u;
+    return set_error(ctx, PT_ERR_TRAVERSAL, "a traversal wave reached its iteration bound (" + std::to_string(ctx->iter_cap) +
+                     " loop iterations): its rays were reported with the closest hit found so far and the rest of its queue as misses, "
+                     "so the frames and ray queries since the last synchronisation are not valid");
+}
+
 int sync_streams(pt_ctx* ctx)
 {
     if (!ctx->pending.empty()) {
@@ -196,7 +205,7 @@ int sync_streams(pt_ctx* ctx)
     for (uint32_t c = PT_MAX_CHAINS; c-- > 0;)
         if (ctx->chain_stream[c]) PT_HIP(ctx, hipStreamSynchronize(ctx->chain_stream[c]));
     ctx->join_pending = false;
-    return PT_OK;
+    return check_fault(ctx);
 }
 
 int join_chains(pt_ctx* ctx)
@@ -267,6 +276,9 @@ int pt_create(int device_ordinal, pt_ctx** out)
     if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
     if (const char* e = getenv("PT_BATCH")) { int v = atoi(e); ctx->batch = v < 1 ? 1u : (v > PT_MAX_BATCH ? (uint32_t)PT_MAX_BATCH : (uint32_t)v); }
     if (es == hipSuccess) es = hipMalloc((void**)&ctx->d_views, sizeof(FrameView) * PT_MAX_BATCH * PT_MAX_CHAINS);
+    if (es == hipSuccess) es = hipHostMalloc((void**)&ctx->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (es == hipSuccess) { *ctx->h_fault = 0u; es = hipHostGetDevicePointer((void**)&ctx->d_fault, ctx->h_fault, 0); }
+    if (const char* e = getenv("PT_ITER_CAP")) { long v = atol(e); if (v >= 1 && v <= (1l << 24)) ctx->iter_cap = (uint32_t)v; }
     hipError_t e1 = hipMalloc((void**)&ctx->d_total_rays, 8);
     hipError_t e2 = hipMalloc((void**)&ctx->d_stats, 128);
     if (es != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) { pt_destroy(ctx); return set_error(nullptr, PT_ERR_HIP, "context allocation failed"); }
@@ -290,6 +302,7 @@ void pt_destroy(pt_ctx* ctx)
     (void)dev_free(ctx->d_suspend);
     (void)dev_free(ctx->d_wave_trace);
     (void)dev_free(ctx->d_total_rays);
+    if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     (void)dev_free(ctx->d_stats);
     for (pt_prof_slot& slot : ctx->prof_slot) {
         for (auto& v : slot.ev)
@@ -517,6 +530,18 @@ int pt_set_params(pt_ctx* ctx, const pt_params* p)
     // the chains' shares of the queue counters are laid out by the number of rounds: frames still running keep theirs
     if ((uint64_t)p->spp_per_frame * p->max_bounces != (uint64_t)ctx->params.spp_per_frame * ctx->params.max_bounces) PT_SYNC(ctx);
     ctx->params = *p;
+    return PT_OK;
+}
+
+int pt_set_precision(pt_ctx* ctx, int mode)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (mode != PT_PRECISION_EXACT && mode != PT_PRECISION_FAST) return set_error(ctx, PT_ERR_INVALID, "pt_set_precision: mode must be PT_PRECISION_EXACT or PT_PRECISION_FAST");
+    if (!ctx->pending.empty()) {      // frames already handed in keep the arithmetic they were traced with
+        int rc = launch_trace(ctx);
+        if (rc) return rc;
+    }
+    ctx->precision = mode;
     return PT_OK;
 }
 

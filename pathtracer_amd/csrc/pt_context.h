@@ -98,10 +98,14 @@ struct pt_ctx {
     size_t wave_trace_len = 0;
     uint32_t wave_trace_rounds = 0, wave_trace_waves = 0;
     unsigned long long* d_total_rays = nullptr;
+    uint32_t* h_fault = nullptr;             // pinned host word the traversal kernels set when a wave reached its iteration bound
+    uint32_t* d_fault = nullptr;             // the same word as the device sees it
+    uint32_t iter_cap = 1u << 24;            // bound of a wave's traversal loop (PT_ITER_CAP in the environment: tests)
     void* noalloc_scratch = nullptr;         // address, on this context's GPU, of the fixed scratch array of pt_intersect_noalloc
     unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested, [2] fetch cursor of pt_debug_intersect
 
     pt_params params{};
+    int precision = PT_PRECISION_EXACT;      // arithmetic of the shading stage (pt_set_precision)
     float camera[80];
     bool camera_set = false;
 
@@ -127,6 +131,7 @@ int launch_postprocess(pt_ctx* ctx, float exposure);
 int env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t w, uint32_t h, uint32_t face_size);
 int env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclination, uint32_t face_size);
 int sync_streams(pt_ctx* ctx);     // host waits for every chain
+int check_fault(pt_ctx* ctx);      // PT_ERR_TRAVERSAL if a traversal wave reached its iteration bound since the last check
 int collect_slot(pt_ctx* ctx, pt_prof_slot& slot);   // waits for that frame, adds it to the timing window
 int join_chains(pt_ctx* ctx);      // main stream waits for the other chains (no host wait)
 int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);

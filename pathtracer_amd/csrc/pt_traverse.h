@@ -407,10 +407,15 @@ PT_DEV void finish_hit(Trav& s)
 // its result; *cursor hands out queue indices (must be 0 at launch), n = queue length.
 // lds_stack points at this lane's column: entry k is lds_stack[k * stride]; ovf points at this lane's
 // column of the wave's global spill area: entry k is ovf[k * 64]; scratch is the wave's PT_SCRATCH_WORDS words of LDS.
+// iter_cap bounds the loop (PT_ITER_CAP_DEFAULT; never reached by a well-formed hierarchy, where a ray takes a few hundred
+// steps at most): a wave that reaches it reports its rays' closest hits so far, reports every ray still in the queue as a
+// miss, so that no hit record is left unwritten, and sets *fault, which the host turns into PT_ERR_TRAVERSAL at its next
+// synchronisation.
+#define PT_ITER_CAP_DEFAULT (1u << 24)
 template <bool STATS, bool CUT, class Fetch, class Emit, class Suspend, class ResumeRecord>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
                        uint32_t* cursor, uint2* lds_stack, int stride, uint2* ovf, uint32_t* scratch, Fetch fetch, Emit emit, Suspend suspend, ResumeRecord resume_record,
-                       uint32_t& stat_nodes, uint32_t& stat_tris, WaveStats* wave_stats = nullptr)
+                       uint32_t& stat_nodes, uint32_t& stat_tris, uint32_t iter_cap, uint32_t* fault, WaveStats* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     uint16_t* owner = reinterpret_cast<uint16_t*>(scratch);
@@ -425,9 +430,9 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
     unsigned long long t_start = 0, t_exh = 0;
     uint32_t ray_steps = 0, ray_steps_max = 0;
     if (STATS && wave_stats) t_start = wall_clock64();
-    // the cap is never reached by a well-formed hierarchy (a ray takes a few hundred steps at most); it only
-    // guarantees that every wave leaves the loop whatever the data
-    for (uint32_t iter = 0; iter < (1u << 24); iter++) {
+    // the cap only guarantees that every wave leaves the loop whatever the data
+    uint32_t iter = 0;
+    for (; iter < iter_cap; iter++) {
         unsigned long long idle = __ballot(!has);
         uint32_t nidle = (uint32_t)__popcll(idle);
         if (!exhausted && nidle >= PT_REFILL_MIN) {
@@ -504,6 +509,24 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
                 if (s.cur == PT_CUR_NONE && s.pend == 0) { emit(my, s); has = false; }
             }
         }
+    }
+    if (iter >= iter_cap) {       // wave-uniform: the loop was cut short
+        if (has) { emit(my, s); has = false; }
+        while (!exhausted) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cursor, 64u);
+            base = __shfl(base, 0);
+            const uint32_t i = base + lane;
+            if (i < n) {
+                v3 o, d;
+                float tmin, tmax;
+                (void)fetch(i, o, d, tmin, tmax);
+                trav_init(s, o, d, tmin, tmax);
+                emit(i, s);
+            }
+            if (base + 64u >= n) exhausted = true;
+        }
+        if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (STATS && wave_stats) {
         unsigned long long t_end = wall_clock64();

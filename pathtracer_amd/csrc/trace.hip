@@ -208,6 +208,8 @@ struct ExtendArgs {
     float4* hits;
     float* hit_det;
     uint2* spill;
+    uint32_t iter_cap;          // bound of a wave's traversal loop
+    uint32_t* fault;            // host-visible word, set when a wave reached the bound
 };
 
 template <bool STATS, bool CUT>
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) PT_EXT_WAVES_ATTR k_extend(SceneVie
     };
     auto resume_record = [&](uint32_t i) { return a.susp_in + ((size_t)ls * a.susp_cap + i) * a.susp_words; };
     trace_wave<STATS, CUT>(sc.nodes, sc.tris, sc.num_tris, n, &a.cursors[ls], stack + threadIdx.x, EXT_BLOCK,
-                           a.spill + (size_t)blockIdx.x * (a.stack_entries * 64) + threadIdx.x, scratch, fetch, emit, suspend, resume_record, sn, st, STATS ? &ws : nullptr);
+                           a.spill + (size_t)blockIdx.x * (a.stack_entries * 64) + threadIdx.x, scratch, fetch, emit, suspend, resume_record, sn, st, a.iter_cap, a.fault, STATS ? &ws : nullptr);
     if (STATS) {
         atomicAdd(&stats[0], (unsigned long long)sn);
         atomicAdd(&stats[1], (unsigned long long)st);
@@ -605,6 +607,8 @@ int launch_trace(pt_ctx* ctx)
             ea.hits = ctx->d_hits;
             ea.hit_det = ctx->d_hit_det;
             ea.spill = spill;
+            ea.iter_cap = ctx->iter_cap;
+            ea.fault = ctx->d_fault;
             unsigned long long* wt = wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr;
             if (counting && ea.next_counts) k_extend<true, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
             else if (counting) k_extend<true, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
@@ -615,7 +619,8 @@ int launch_trace(pt_ctx* ctx)
             q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
             q.stA_in = ctx->d_stA[in]; q.stB_in = ctx->d_stB[in];
             q.stA_out = ctx->d_stA[out]; q.stB_out = ctx->d_stB[out];
-            k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
+            if (ctx->precision == PT_PRECISION_FAST) fast::k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
+            else k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
             PT_HIP(ctx, mark());
         }
         {
@@ -646,7 +651,8 @@ int launch_resolve(pt_ctx* ctx)
 
 // ---- inspection hooks --------------------------------------------------------------------------
 __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uint32_t n, uint32_t* cursor, const float4* __restrict__ rays,
-                                                                uint32_t* __restrict__ out, uint2* spill, uint32_t stack_entries, unsigned long long* stats)
+                                                                uint32_t* __restrict__ out, uint2* spill, uint32_t stack_entries, unsigned long long* stats,
+                                                                uint32_t iter_cap, uint32_t* fault)
 {
     __shared__ uint2 stack[PT_STACK_LDS * EXT_BLOCK];
     __shared__ __attribute__((aligned(16))) uint32_t scratch[PT_SCRATCH_WORDS];
@@ -670,7 +676,7 @@ __global__ void __launch_bounds__(EXT_BLOCK) k_debug_intersect(SceneView sc, uin
             if (h.tri == MISS) { o[0] = f2u(h.t); o[1] = 0; o[2] = 0; o[3] = MISS; o[4] = MISS; }   // h.t is still tmax
             else { o[0] = f2u(h.t); o[1] = f2u(h.u); o[2] = f2u(h.v); o[3] = sc.tris[h.tri].submesh; o[4] = sc.tris[h.tri].prim; }
         },
-        [&](uint32_t, const Trav&, const uint2*, int, const uint2*) {}, [&](uint32_t) { return (const uint32_t*)nullptr; }, sn, st);
+        [&](uint32_t, const Trav&, const uint2*, int, const uint2*) {}, [&](uint32_t) { return (const uint32_t*)nullptr; }, sn, st, iter_cap, fault);
     atomicAdd(&stats[0], (unsigned long long)sn);
     atomicAdd(&stats[1], (unsigned long long)st);
 }
@@ -693,38 +699,45 @@ __global__ void k_debug_math(int fn, uint32_t n, const float* __restrict__ x, co
     }
 }
 
-PT_DEV Surf surf_from(const float* s)
-{
-    Surf p;
-    p.albedo = V3(s[0], s[1], s[2]);
-    p.metallic = s[3]; p.roughness = s[4]; p.subsurface = s[5]; p.specularTint = s[6];
-    p.sheen = s[7]; p.sheenTint = s[8]; p.clearcoat = s[9]; p.clearcoatRoughness = s[10];
-    p.specTrans = s[11]; p.ior = s[12]; p.ax = s[13]; p.ay = s[14]; p.eta = s[15];
-    return p;
-}
+// one body for both arithmetic namespaces: A = ptd (bit-exact) or ptd::fast
+#define PT_DEBUG_DISNEY_BODY(NS)                                                                                          \
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;                                                                    \
+    if (i >= n) return;                                                                                                    \
+    const float* s = surf + (size_t)i * 17;                                                                                \
+    NS::Surf p;                                                                                                            \
+    p.albedo = NS::V3(s[0], s[1], s[2]);                                                                                   \
+    p.metallic = s[3]; p.roughness = s[4]; p.subsurface = s[5]; p.specularTint = s[6];                                     \
+    p.sheen = s[7]; p.sheenTint = s[8]; p.clearcoat = s[9]; p.clearcoatRoughness = s[10];                                  \
+    p.specTrans = s[11]; p.ior = s[12]; p.ax = s[13]; p.ay = s[14]; p.eta = s[15];                                         \
+    NS::v3 v = NS::V3(V[3 * i], V[3 * i + 1], V[3 * i + 2]), nn = NS::V3(N[3 * i], N[3 * i + 1], N[3 * i + 2]);            \
+    float pd;                                                                                                              \
+    NS::v3 r;                                                                                                              \
+    if (sample) {                                                                                                          \
+        uint32_t seed = seeds[i];                                                                                          \
+        NS::v3 L;                                                                                                          \
+        r = NS::disney_sample(p, v, nn, L, pd, seed);                                                                      \
+        seeds[i] = seed;                                                                                                   \
+        Lout[3 * i] = L.x; Lout[3 * i + 1] = L.y; Lout[3 * i + 2] = L.z;                                                   \
+    } else {                                                                                                               \
+        r = NS::disney_eval(p, v, nn, NS::V3(Lin[3 * i], Lin[3 * i + 1], Lin[3 * i + 2]), pd);                             \
+    }                                                                                                                      \
+    f[3 * i] = r.x; f[3 * i + 1] = r.y; f[3 * i + 2] = r.z;                                                                \
+    pdf[i] = pd;
 
 __global__ void k_debug_disney(bool sample, uint32_t n, const float* __restrict__ surf, const float* __restrict__ V,
                                const float* __restrict__ N, const float* __restrict__ Lin, uint32_t* seeds,
                                float* __restrict__ f, float* __restrict__ Lout, float* __restrict__ pdf)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Surf p = surf_from(surf + (size_t)i * 17);
-    v3 v = V3(V[3 * i], V[3 * i + 1], V[3 * i + 2]), nn = V3(N[3 * i], N[3 * i + 1], N[3 * i + 2]);
-    float pd;
-    v3 r;
-    if (sample) {
-        uint32_t seed = seeds[i];
-        v3 L;
-        r = disney_sample(p, v, nn, L, pd, seed);
-        seeds[i] = seed;
-        Lout[3 * i] = L.x; Lout[3 * i + 1] = L.y; Lout[3 * i + 2] = L.z;
-    } else {
-        r = disney_eval(p, v, nn, V3(Lin[3 * i], Lin[3 * i + 1], Lin[3 * i + 2]), pd);
-    }
-    f[3 * i] = r.x; f[3 * i + 1] = r.y; f[3 * i + 2] = r.z;
-    pdf[i] = pd;
+    PT_DEBUG_DISNEY_BODY(ptd)
 }
+
+__global__ void k_debug_disney_fast(bool sample, uint32_t n, const float* __restrict__ surf, const float* __restrict__ V,
+                                    const float* __restrict__ N, const float* __restrict__ Lin, uint32_t* seeds,
+                                    float* __restrict__ f, float* __restrict__ Lout, float* __restrict__ pdf)
+{
+    PT_DEBUG_DISNEY_BODY(ptd::fast)
+}
+#undef PT_DEBUG_DISNEY_BODY
 
 template <class T>
 struct Tmp {
@@ -750,14 +763,14 @@ int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, 
         int rc = ensure_spill(ctx, blocks);
         if (rc) return rc;
     }
-    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(ctx->d_stats + 2), d_rays.p, d_out.p, ctx->d_spill, ctx->stack_entries, ctx->d_stats);
+    if (n) k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(ctx->d_stats + 2), d_rays.p, d_out.p, ctx->d_spill, ctx->stack_entries, ctx->d_stats, ctx->iter_cap, ctx->d_fault);
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipMemcpyAsync(hits, d_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, st));
     unsigned long long hs[2] = {0, 0};
     PT_HIP(ctx, hipMemcpyAsync(hs, ctx->d_stats, 16, hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipStreamSynchronize(st));
     if (counters) { counters[0] = hs[0]; counters[1] = hs[1]; }
-    return PT_OK;
+    return check_fault(ctx);
 }
 
 // ---- closest hits without any allocation ------------------------------------------------------------
@@ -799,7 +812,7 @@ int intersect_noalloc(pt_ctx* ctx, const float* d_rays, uint32_t n, uint32_t* d_
     uint32_t blocks = (n + EXT_BLOCK - 1) / EXT_BLOCK;
     if (blocks > PT_NOALLOC_WAVES) blocks = PT_NOALLOC_WAVES;
     k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(stats + 2), reinterpret_cast<const float4*>(d_rays), d_hits,
-                                                    reinterpret_cast<uint2*>(base + PT_NOALLOC_HEADER), ctx->stack_entries, stats);
+                                                    reinterpret_cast<uint2*>(base + PT_NOALLOC_HEADER), ctx->stack_entries, stats, ctx->iter_cap, ctx->d_fault);
     PT_HIP(ctx, hipGetLastError());
     ctx->main_dirty = true;
     return PT_OK;
@@ -841,7 +854,8 @@ int debug_disney(pt_ctx* ctx, bool sample, uint32_t n, const float* surf, const 
     PT_HIP(ctx, hipMemcpyAsync(dN.p, N, (size_t)n * 12, hipMemcpyHostToDevice, st));
     if (Lin) PT_HIP(ctx, hipMemcpyAsync(dL.p, Lin, (size_t)n * 12, hipMemcpyHostToDevice, st));
     if (seeds) PT_HIP(ctx, hipMemcpyAsync(dseed.p, seeds, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    if (n) k_debug_disney<<<(n + 255) / 256, 256, 0, st>>>(sample, n, dsurf.p, dV.p, dN.p, dL.p, dseed.p, df.p, dLo.p, dpdf.p);
+    if (n && ctx->precision == PT_PRECISION_FAST) k_debug_disney_fast<<<(n + 255) / 256, 256, 0, st>>>(sample, n, dsurf.p, dV.p, dN.p, dL.p, dseed.p, df.p, dLo.p, dpdf.p);
+    else if (n) k_debug_disney<<<(n + 255) / 256, 256, 0, st>>>(sample, n, dsurf.p, dV.p, dN.p, dL.p, dseed.p, df.p, dLo.p, dpdf.p);
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipMemcpyAsync(f, df.p, (size_t)n * 12, hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipMemcpyAsync(pdf, dpdf.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));

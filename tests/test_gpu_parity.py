@@ -427,6 +427,40 @@ def test_image_does_not_depend_on_ray_suspension(cornell, cameras, monkeypatch, 
         b.close()
 
 
+def test_iteration_bound_of_the_traversal_is_reported(cornell, cameras, monkeypatch):
+    """A traversal wave leaves its loop after a fixed number of iterations whatever the data (2^24 by default, which no
+    well-formed hierarchy reaches).  With the bound forced down to 3 (PT_ITER_CAP) every wave reaches it: the waves still
+    write every hit record (closest hit so far, misses for rays not yet fetched), and the next synchronising call returns
+    PT_ERR_TRAVERSAL instead of handing out the frame silently.  The context stays usable."""
+    from pathtracer_amd.backend import Backend
+    monkeypatch.setenv("PT_ITER_CAP", "3")
+    b = Backend(0)
+    try:
+        b.scene_upload(cornell)
+        b.build_accel()
+        b.resize(64, 64)
+        b.set_camera(cameras["64x64"])
+        b.set_params(Params.reference(spp_per_frame=1, max_bounces=4))
+        b.trace(1)
+        with pytest.raises(BackendError) as e:
+            b.sync()
+        assert e.value.code == 6 and "iteration bound" in str(e.value)
+        b.sync()                                 # the fault was reported once
+        rays = random_rays(np.random.default_rng(3), 1000, -0.3, 0.5)
+        with pytest.raises(BackendError) as e:
+            b.debug_intersect(rays)
+        assert e.value.code == 6
+    finally:
+        b.close()
+    monkeypatch.delenv("PT_ITER_CAP")
+    b = Backend(0)
+    try:
+        o, rays = render_pair(b, cornell, cameras["64x64"], 64, 64, (1, 2), spp_per_frame=1, max_bounces=4)
+        assert_same_frame(b, o, rays)
+    finally:
+        b.close()
+
+
 def test_cornell_512_config_and_golden_ids(backend, cornell, cameras):
     # the CPU-runnable configuration: Cornell box 512x512, 1 spp, 4 bounces
     o, rays = render_pair(backend, cornell, cameras["512x512"], 512, 512, (1, 2), spp_per_frame=1, max_bounces=4)
