@@ -237,6 +237,14 @@ void* pt_stream(pt_ctx* ctx);
  * without blocking the host.  For callers that write the bound images on a stream of their own, e.g. a collective
  * (RCCL reduce of the accumulation image, multi-GPU merge) followed by pt_resolve. */
 int pt_wait_stream(pt_ctx* ctx, void* stream);
+/* Multi-GPU merge: one ncclReduce (sum, float32, width*height*4 values, in place) of the accumulation image currently
+ * rendered into, to rank `root` of `nccl_comm` (an ncclComm_t of RCCL as void*), on the context's main stream after every frame
+ * issued so far; asynchronous.  Every rank of the communicator calls it, one context per GPU; afterwards the root calls
+ * pt_resolve.  A frame's samples depend only on (pixel, FrameIndex) and frames add (RayGen.glsl:314-315,351-359), so ranks
+ * that rendered disjoint sets of frame indices merge to exactly the single-GPU sample set.  The reference is single-GPU
+ * and has no counterpart.  RCCL is not linked into this library: ncclReduce is taken from the RCCL already present in the
+ * process (linked or loaded), else from librccl.so on the loader's path, or from the file PT_RCCL_LIB names. */
+int pt_reduce_accum(pt_ctx* ctx, void* nccl_comm, int root);
 /* device pointers of the images currently rendered into */
 void* pt_device_image(pt_ctx* ctx);
 void* pt_device_accum(pt_ctx* ctx);
@@ -253,8 +261,10 @@ int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hit
  * (one per GPU, held until the process ends).  Limits, refused with PT_ERR_TOO_LARGE: n <= 2^24 rays; a hierarchy
  * of at most 18 levels of 8-wide nodes (pt_accel_stats.max_depth; the 3 M-triangle test scene has 11).
  * Asynchronous on the context's main stream: read device_hits after pt_sync or behind pt_stream.  Frames queued
- * by pt_trace must have been flushed (pt_sync) before the call.  Every call on a GPU shares that GPU's array:
- * calls that overlap on one GPU (two contexts, or streams of the caller's own) race. */
+ * by pt_trace must have been flushed (pt_sync) before the call.  device_hits must not overlap device_rays (PT_ERR_INVALID).
+ * Every call on a GPU shares that GPU's array: a call is refused with PT_ERR_INVALID while a query of another context on the
+ * same GPU has not finished (queries of one context follow each other on its stream); work the caller orders behind the
+ * query on streams of its own is the caller's to keep apart. */
 int pt_intersect_noalloc(pt_ctx* ctx, const float* device_rays, uint32_t n, uint32_t* device_hits);
 /* the deterministic functions used by the kernels: fn 0 sin, 1 cos, 2 log, 3 exp, 4 pow(x,y), 5 atan2(x,y),
  * 6 acos, 7 tan, 8 binary32 -> binary16 -> binary32 rounding */

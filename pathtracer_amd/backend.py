@@ -18,7 +18,7 @@ EXPORTS = [
     "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_set_precision", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
     "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
-    "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_wait_stream", "pt_device_image", "pt_device_accum",
+    "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_wait_stream", "pt_reduce_accum", "pt_device_image", "pt_device_accum",
     "pt_debug_intersect", "pt_intersect_noalloc", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
 ]
 
@@ -95,6 +95,7 @@ def load_library():
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
     lib.pt_wait_stream.argtypes = [vp, vp]
+    lib.pt_reduce_accum.argtypes = [vp, vp, C.c_int]
     lib.pt_debug_intersect.argtypes = [vp, fp, C.c_uint32, up, C.POINTER(C.c_uint64)]
     lib.pt_intersect_noalloc.argtypes = [vp, vp, C.c_uint32, vp]
     lib.pt_debug_math.argtypes = [vp, C.c_int, fp, fp, fp, C.c_uint32]
@@ -271,6 +272,10 @@ class Backend:
     def wait_stream(self, stream):
         """Later work of the context runs after what is enqueued so far on `stream` (hipStream_t as int; 0 = null stream)."""
         self._check(self.lib.pt_wait_stream(self.h, C.c_void_p(stream)))
+
+    def reduce_accum(self, nccl_comm, root=0):
+        """One in-place RCCL sum-reduce of the accumulation image to `root` (nccl_comm: ncclComm_t as int), on the context's stream."""
+        self._check(self.lib.pt_reduce_accum(self.h, C.c_void_p(nccl_comm), int(root)))
 
     def device_image(self):
         return self.lib.pt_device_image(self.h)

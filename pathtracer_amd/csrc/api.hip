@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 
 namespace ptd {
@@ -294,6 +295,7 @@ void pt_destroy(pt_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)sync_streams(ctx);
+    noalloc_release(ctx);
     free_scene(ctx);
     free_images(ctx);
     (void)dev_free(ctx->d_counts);
@@ -744,6 +746,65 @@ int pt_wait_stream(pt_ctx* ctx, void* stream)
     ctx->main_dirty = true;             // the other chains are ordered after the main stream at the next launch
     return PT_OK;
 }
+// ncclReduce of the RCCL the caller's communicator belongs to.  RCCL is not linked: a single-GPU user needs none.  The
+// symbol is looked up in this order: PT_RCCL_LIB (a path), the process's global symbols (an application linked against
+// RCCL), an RCCL that is already loaded under its usual names (a Python process whose torch brought its own), and last a
+// fresh load of librccl.so from the loader's search path.
+typedef int (*nccl_reduce_fn)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, int root, void* comm, hipStream_t stream);
+typedef const char* (*nccl_error_fn)(int);
+static nccl_reduce_fn g_nccl_reduce = nullptr;
+static nccl_error_fn g_nccl_error = nullptr;
+static std::string g_nccl_source;
+
+static bool resolve_rccl(std::string& why)
+{
+    if (g_nccl_reduce) return true;
+    void* h = nullptr;
+    if (const char* path = getenv("PT_RCCL_LIB")) {
+        h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { why = std::string("PT_RCCL_LIB: ") + dlerror(); return false; }
+        g_nccl_source = path;
+    }
+    if (!h) {
+        if (void* f = dlsym(RTLD_DEFAULT, "ncclReduce")) {
+            g_nccl_reduce = (nccl_reduce_fn)f;
+            g_nccl_error = (nccl_error_fn)dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+            g_nccl_source = "global symbols of the process";
+            return true;
+        }
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)
+            if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) g_nccl_source = std::string(n) + " (already loaded)";
+        for (const char* n : names)
+            if (!h && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) g_nccl_source = n;
+    }
+    if (!h) { why = "RCCL not found: link the application against librccl, load it before this call, or set PT_RCCL_LIB"; return false; }
+    g_nccl_reduce = (nccl_reduce_fn)dlsym(h, "ncclReduce");
+    g_nccl_error = (nccl_error_fn)dlsym(h, "ncclGetErrorString");
+    if (!g_nccl_reduce) { why = g_nccl_source + " has no ncclReduce"; return false; }
+    return true;
+}
+
+int pt_reduce_accum(pt_ctx* ctx, void* nccl_comm, int root)
+{
+    if (!ctx || !nccl_comm) return PT_ERR_INVALID;
+    if (!ctx->width) return set_error(ctx, PT_ERR_INVALID, "pt_reduce_accum: call pt_resize first");
+    if (root < 0) return set_error(ctx, PT_ERR_INVALID, "pt_reduce_accum: root must be a rank of the communicator");
+    std::string why;
+    if (!resolve_rccl(why)) return set_error(ctx, PT_ERR_INVALID, "pt_reduce_accum: " + why);
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = join_chains(ctx);          // queued frames are launched and every chain's work is ordered before the reduce
+    if (rc) return rc;
+    ctx->main_dirty = true;             // later frames of the other chains run after the reduce
+    const size_t count = (size_t)ctx->width * ctx->height * 4;
+    const int NCCL_FLOAT32 = 7, NCCL_SUM = 0;
+    int nrc = g_nccl_reduce(ctx->d_accum, ctx->d_accum, count, NCCL_FLOAT32, NCCL_SUM, root, nccl_comm, ctx->stream);
+    if (nrc != 0)
+        return set_error(ctx, PT_ERR_HIP, std::string("pt_reduce_accum: ncclReduce failed: ") + (g_nccl_error ? g_nccl_error(nrc) : std::to_string(nrc).c_str()) +
+                         " (RCCL from " + g_nccl_source + ")");
+    return PT_OK;
+}
+
 void* pt_device_image(pt_ctx* ctx) { return ctx ? (void*)ctx->d_image : nullptr; }
 void* pt_device_accum(pt_ctx* ctx) { return ctx ? (void*)ctx->d_accum : nullptr; }
 

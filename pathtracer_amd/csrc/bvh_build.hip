@@ -30,6 +30,14 @@
 #include <utility>
 #include <vector>
 
+// The bottom-up passes below hand data from the thread that arrives first at a node to the one that arrives second with
+// relaxed agent-scope atomics and an inline "s_waitcnt vmcnt(0)" as the release: that is only a release on targets whose
+// stores count in vmcnt (the gfx9 family); on a target with a separate store counter the hand-over would publish node
+// boxes and children before the stores land.  This file is gfx950 code.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "bvh_build.hip relies on gfx950 memory-counter semantics (s_waitcnt vmcnt(0) as the release of a store): build with --offload-arch=gfx950"
+#endif
+
 namespace ptd {
 
 static constexpr uint32_t NONE = 0xFFFFFFFFu;

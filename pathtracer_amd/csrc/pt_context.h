@@ -102,6 +102,7 @@ struct pt_ctx {
     uint32_t* d_fault = nullptr;             // the same word as the device sees it
     uint32_t iter_cap = 1u << 24;            // bound of a wave's traversal loop (PT_ITER_CAP in the environment: tests)
     void* noalloc_scratch = nullptr;         // address, on this context's GPU, of the fixed scratch array of pt_intersect_noalloc
+    hipEvent_t noalloc_done = nullptr;       // recorded after each pt_intersect_noalloc launch: other contexts on the GPU check it
     unsigned long long* d_stats = nullptr;  // [0] nodes visited, [1] triangles tested, [2] fetch cursor of pt_debug_intersect
 
     pt_params params{};
@@ -136,6 +137,7 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot);   // waits for that frame, ad
 int join_chains(pt_ctx* ctx);      // main stream waits for the other chains (no host wait)
 int debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t* hits, uint64_t* counters);
 int noalloc_init(pt_ctx* ctx);
+void noalloc_release(pt_ctx* ctx);
 int intersect_noalloc(pt_ctx* ctx, const float* d_rays, uint32_t n, uint32_t* d_hits);
 int debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, uint32_t n);
 int debug_disney(pt_ctx* ctx, bool sample, uint32_t n, const float* surf, const float* V, const float* N,

@@ -33,6 +33,7 @@
 #include "pt_traverse.h"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace ptd {
 
@@ -784,6 +785,13 @@ static constexpr size_t PT_NOALLOC_HEADER = 256;
 static constexpr size_t PT_NOALLOC_BYTES = PT_NOALLOC_HEADER + (size_t)PT_NOALLOC_WAVES * PT_NOALLOC_STACK * 64 * sizeof(uint2);
 static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_BYTES];
 
+// Who used a GPU's array last: a query of another context that has not finished yet would share the fetch cursor and
+// the spill area with a new one, and the result would be wrong hits, not an error.  Queries of one context follow each
+// other on its stream and need no check.
+struct NoallocOwner { pt_ctx* ctx = nullptr; hipEvent_t done = nullptr; };
+static std::mutex g_noalloc_mutex;
+static NoallocOwner g_noalloc_owner[64];
+
 // the array's address on the device that is current; called once per context, at pt_create
 int noalloc_init(pt_ctx* ctx)
 {
@@ -791,7 +799,17 @@ int noalloc_init(pt_ctx* ctx)
     PT_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return set_error(ctx, PT_ERR_HIP, "hipGetSymbolAddress returned a null address for the ray-query scratch");
     ctx->noalloc_scratch = ptr;
+    PT_HIP(ctx, hipEventCreateWithFlags(&ctx->noalloc_done, hipEventDisableTiming));    // made here, so that the query itself creates nothing
     return PT_OK;
+}
+
+// pt_destroy: the context's streams are idle by now
+void noalloc_release(pt_ctx* ctx)
+{
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (ctx->device >= 0 && ctx->device < 64 && g_noalloc_owner[ctx->device].ctx == ctx) g_noalloc_owner[ctx->device] = NoallocOwner();
+    if (ctx->noalloc_done) (void)hipEventDestroy(ctx->noalloc_done);
+    ctx->noalloc_done = nullptr;
 }
 
 int intersect_noalloc(pt_ctx* ctx, const float* d_rays, uint32_t n, uint32_t* d_hits)
@@ -801,7 +819,19 @@ int intersect_noalloc(pt_ctx* ctx, const float* d_rays, uint32_t n, uint32_t* d_
                          " levels; the fixed scratch holds traversal stacks for at most 18");
     if (n > PT_NOALLOC_MAX_RAYS) return set_error(ctx, PT_ERR_TOO_LARGE, "pt_intersect_noalloc: more than 2^24 rays in one call");
     if (!ctx->pending.empty()) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: frames are queued; call pt_sync first");
-    if (!ctx->noalloc_scratch) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: scratch address missing");
+    if (!ctx->noalloc_scratch || !ctx->noalloc_done) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: scratch address missing");
+    {
+        // the kernel's arguments are __restrict__: the hit records must not overlap the rays
+        const uintptr_t r0 = (uintptr_t)d_rays, r1 = r0 + (size_t)n * 32, h0 = (uintptr_t)d_hits, h1 = h0 + (size_t)n * 20;
+        if (n && r0 < h1 && h0 < r1) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: device_hits overlaps device_rays");
+    }
+    if (ctx->device < 0 || ctx->device >= 64) return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: device ordinal beyond 63");
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    NoallocOwner& owner = g_noalloc_owner[ctx->device];
+    if (owner.ctx && owner.ctx != ctx && hipEventQuery(owner.done) == hipErrorNotReady)
+        return set_error(ctx, PT_ERR_INVALID, "pt_intersect_noalloc: a query of another context is still running on this GPU and uses the same scratch array; "
+                                              "wait for it (pt_sync on that context) first");
+    (void)hipGetLastError();            // hipEventQuery's "not ready" is not an error of this call
     int rc = join_chains(ctx);          // event record + stream wait only
     if (rc) return rc;
     if (n == 0) return PT_OK;
@@ -814,6 +844,9 @@ int intersect_noalloc(pt_ctx* ctx, const float* d_rays, uint32_t n, uint32_t* d_
     k_debug_intersect<<<blocks, EXT_BLOCK, 0, st>>>(scene_view(ctx), n, reinterpret_cast<uint32_t*>(stats + 2), reinterpret_cast<const float4*>(d_rays), d_hits,
                                                     reinterpret_cast<uint2*>(base + PT_NOALLOC_HEADER), ctx->stack_entries, stats, ctx->iter_cap, ctx->d_fault);
     PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventRecord(ctx->noalloc_done, st));
+    owner.ctx = ctx;
+    owner.done = ctx->noalloc_done;
     ctx->main_dirty = true;
     return PT_OK;
 }

@@ -563,6 +563,48 @@ def test_benchmark_workload_at_full_size(backend, workload):
     o.close()
 
 
+def test_long_progressive_run_keeps_its_state(backend):
+    """4096 samples per pixel, the progressive configuration: frames 1..4090 on the GPU alone (over 500 batches of
+    launches through the queues, the suspension records and the counters), then the accumulation image goes to the oracle and
+    frames 4091..4093 run on both: every bit equal, so nothing drifted on the way.  1920x1080, Sponza-class, 8 bounces."""
+    sc = procedural.sponza_class()
+    W, H, N = 1920, 1080, 4090
+    cam = procedural.sponza_camera(W, H)
+    p = Params.reference(spp_per_frame=1, max_bounces=8)
+    backend.scene_upload(sc)
+    backend.build_accel()
+    backend.resize(W, H)
+    backend.set_camera(cam)
+    backend.set_params(p)
+    counts = [backend.ray_count()]
+    for f in range(1, N + 1):
+        backend.trace(f)
+        if f % 1024 == 0:
+            counts.append(backend.ray_count())
+    counts.append(backend.ray_count())
+    steps = np.diff(counts)
+    assert (steps[:-1] > 0).all() and abs(steps[1] - steps[2]) < 0.01 * steps[1]      # the same work per thousand frames
+    acc = backend.read_accum()
+    img = backend.read_image()
+    assert (acc[..., 3] == N - 1).all()                       # frame 1 clears, every later frame adds one sample
+    assert np.isfinite(acc).all() and np.isfinite(img).all()
+    assert not ((img[..., 0] == 1.0) & (img[..., 1] == 0.0) & (img[..., 2] == 0.0)).any()     # no NaN pixel was painted red
+    o = oracle_lib.Oracle(sc)
+    o.resize(W, H)
+    o.set_camera(cam)
+    o.set_params(p)
+    o.write_accum(acc)
+    r0 = backend.ray_count()
+    for f in (N + 1, N + 2, N + 3):
+        backend.trace(f)
+        o.trace(f)
+    assert backend.ray_count() - r0 == o.ray_count()
+    assert np.array_equal(bits(backend.read_accum()), bits(o.read_accum()))
+    assert np.array_equal(bits(backend.read_image()), bits(o.read_image()))
+    assert np.array_equal(backend.read_primary_ids(), o.read_primary_ids())
+    o.close()
+
+
 def test_large_scene(backend):
     """The Bistro-class street: 2.97 M triangles, an 11-level hierarchy that outgrows every cache, long grazing rays
     (the longest traversals suspend and spill).  Ray count, primary ids and every pixel's bits equal the oracle's."""
