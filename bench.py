@@ -174,7 +174,10 @@ class Case:
         b.scene_upload(self.scene)
         self.first_build_ms = b.build_accel(args.build_flags).build_ms     # includes the allocator's first touches
         self.accel = b.build_accel(args.build_flags)                       # the same build again: its steady-state time
-        if args.sky == "preetham":
+        # the Cornell box opens sideways, and the reference's Preetham shader has no values below the horizon (B / cos(theta) at
+        # theta = pi / 2: NaN texels), so that scene keeps the constant sky; the atria and the street see the sky from below
+        self.sky = "white" if name == "cornell" else args.sky
+        if self.sky == "preetham":
             b.env_preetham(*SKY)
             self.sky_text = "Preetham sky (turbidity %g, azimuth %g, inclination %g) as a %d-texel cube x10" % SKY
         else:
@@ -198,6 +201,11 @@ class Case:
         a = self.accel
         return {"nodes": a.num_nodes, "levels": a.max_depth, "build_ms": round(a.build_ms, 3), "first_build_ms": round(self.first_build_ms, 3),
                 "sah_cost": round(a.sah_cost, 2), "references": a.num_references}
+
+    def nan_pixels(self):
+        """Pixels the last frame painted red because their colour was NaN (RayGen.glsl:369-370)."""
+        im = self.r.image
+        return int(((im[..., 0] == 1.0) & (im[..., 1] == 0.0) & (im[..., 2] == 0.0) & (im[..., 3] == 1.0)).sum().item())
 
     def close(self):
         self.b.close()
@@ -302,7 +310,7 @@ def cpu_baseline(case, args, steps):
     from tests import oracle_lib
     threads, nproc, aff = host_threads()
     scene = case.scene
-    if args.sky == "preetham":
+    if case.sky == "preetham":
         scene.env = oracle_lib.preetham_sky(*SKY)      # the oracle's own sky pass (bit-equal to the GPU's, tests/test_gpu_parity.py)
     o = oracle_lib.Oracle(scene, threads=threads)
     o.resize(case.width, case.height)
@@ -416,6 +424,7 @@ def main():
 
     headline = Case(args, "gltf" if args.gltf else args.workload, args.width, args.height, local_rank, device, gltf=args.gltf)
     dt, rays, phases, frames = timed(headline, args.steps, args.warmup)
+    nan_pixels = headline.nan_pixels() if world == 1 else None
     stat = torch.tensor([dt, phases[0], phases[1], phases[2], float(rays)], dtype=torch.float64, device="cpu" if rehearse else device)
     if world > 1:
         tmax = stat[0:4].clone()
@@ -438,7 +447,7 @@ def main():
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": headline.describe(args.bounces),
-                       "rays_per_step_per_gpu": int(rays / args.steps), "triangles": headline.accel.num_triangles,
+                       "rays_per_step_per_gpu": int(rays / args.steps), "triangles": headline.accel.num_triangles, "nan_pixels": nan_pixels,
                        "hierarchy": headline.hierarchy(),
                        "shading_arithmetic": "stated tolerance (pt_set_precision 1)" if args.precision else "bit-exact against the CPU oracle (0 ulp)",
                        "parallelism": "frame-index stripes per GPU, scene replicated" + (", one reduce of the accumulation image (%s)" % reduce_backend if world > 1 else "")},
@@ -464,9 +473,10 @@ def main():
                 continue
             c = Case(args, name, w, h, local_rank, device)
             d, n, _, fr = timed(c, nother, 4)
+            nanpx = c.nan_pixels()
             rl = profile_case(c, fr[:8], args, n / d)
             others.append({"workload": c.describe(args.bounces), "value": round(n / d / 1e6, 2), "unit": "Mrays/s", "steps": nother, "warmup": 4,
-                           "ms_per_step": round(d / nother * 1e3, 4), "rays_per_step": int(n / nother), "triangles": c.accel.num_triangles,
+                           "ms_per_step": round(d / nother * 1e3, 4), "rays_per_step": int(n / nother), "triangles": c.accel.num_triangles, "nan_pixels": nanpx,
                            "hierarchy": c.hierarchy(),
                            "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "counters_stale", "avg_launch_ms", "nodes_per_ray", "tris_per_ray", "bytes_per_ray", "hbm", "valu")}})
             c.close()

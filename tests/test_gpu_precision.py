@@ -97,7 +97,8 @@ def test_frame_primary_ids_and_one_bounce_radiance(backend, cornell, cameras):
     W, H = 256, 256
     backend.scene_upload(cornell)
     backend.build_accel()
-    backend.env_preetham(3.14, 0.0, 0.0, 256)
+    img = np.exp(np.random.default_rng(9).uniform(-2, 3, (64, 128, 4))).astype(np.float32)
+    backend.env_from_equirect(img, 64)            # a sky that differs from texel to texel (and is finite everywhere)
     cam = cameras["512x512"]
     out = {}
     for mode in (EXACT, FAST):
