@@ -76,10 +76,11 @@ __global__ void k_world_tris(uint32_t n, uint32_t ns, const uint32_t* __restrict
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     if (g < n) {
-        uint32_t s, prim;
+        uint32_t s, prim, code = 0;
         if (REFIT) {
             s = tris[g].submesh;
             prim = tris[g].prim;
+            code = tris[g].pad;         // a reference to a part of a split triangle: barycentric bounds of the part (part_code)
         } else {
             // submesh s with sub_tri_offset[s] <= g < sub_tri_offset[s+1]
             uint32_t a = 0, b = ns;
@@ -101,11 +102,27 @@ __global__ void k_world_tris(uint32_t n, uint32_t ns, const uint32_t* __restrict
         TriRec t;
         t.v0x = w[0].x; t.v0y = w[0].y; t.v0z = w[0].z; t.submesh = s;
         t.v1x = w[1].x; t.v1y = w[1].y; t.v1z = w[1].z; t.prim = prim;
-        t.v2x = w[2].x; t.v2y = w[2].y; t.v2z = w[2].z; t.pad = 0;
+        t.v2x = w[2].x; t.v2y = w[2].y; t.v2z = w[2].z; t.pad = code;
         tris[g] = t;
         lo[0] = fminf(fminf(w[0].x, w[1].x), w[2].x); hi[0] = fmaxf(fmaxf(w[0].x, w[1].x), w[2].x);
         lo[1] = fminf(fminf(w[0].y, w[1].y), w[2].y); hi[1] = fmaxf(fmaxf(w[0].y, w[1].y), w[2].y);
         lo[2] = fminf(fminf(w[0].z, w[1].z), w[2].z); hi[2] = fmaxf(fmaxf(w[0].z, w[1].z), w[2].z);
+        if (REFIT && code != 0u) {
+            // the part lies inside the parallelogram of its (u, v) bounds (see part_code), whose image under the new transform is
+            // spanned by four corner points; their box, widened by the rounding of the corner arithmetic, cut to the triangle's own box
+            const float u0 = (float)(code & 127u) * (1.0f / 127.0f), v0 = (float)((code >> 7) & 127u) * (1.0f / 127.0f);
+            const float u1 = (float)((code >> 14) & 127u) * (1.0f / 127.0f), v1 = (float)((code >> 21) & 127u) * (1.0f / 127.0f);
+            const int org = (int)(code >> 28) - 1;
+            const v3 o = w[org], e1 = w[(org + 1) % 3] - o, e2 = w[(org + 2) % 3] - o;
+            const v3 c00 = o + e1 * u0 + e2 * v0, c10 = o + e1 * u1 + e2 * v0, c01 = o + e1 * u0 + e2 * v1, c11 = o + e1 * u1 + e2 * v1;
+            for (int k = 0; k < 3; k++) {
+                const float a0 = comp(c00, k), a1 = comp(c10, k), a2 = comp(c01, k), a3 = comp(c11, k);
+                const float pl = fminf(fminf(a0, a1), fminf(a2, a3)), ph = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                const float slack = (fabsf(lo[k]) + fabsf(hi[k]) + (hi[k] - lo[k])) * 0x1p-20f;
+                lo[k] = fmaxf(lo[k], pl - slack);
+                hi[k] = fminf(hi[k], ph + slack);
+            }
+        }
         // a triangle with a NaN or infinite coordinate can never be hit (every test on it compares false): it gets the
         // empty box, the identity of box union, so that it neither moves the scene bounds nor attracts a ray
         float sum = 0.0f;
@@ -149,8 +166,41 @@ __global__ void k_world_tris(uint32_t n, uint32_t ns, const uint32_t* __restrict
 #define PT_SPLIT_WASTE 4.0f
 #endif
 
-// bounds of the part of triangle (a, b, c) inside the box [clo, chi]; false if there is none
-__device__ bool clip_bounds(v3 a, v3 b, v3 c, const float* clo, const float* chi, float* olo, float* ohi)
+// A reference's part of its triangle as bounds on the weights (u, v) of the part's points in P = o + u e1 + v e2, where o is the
+// triangle's vertex whose angle is closest to a right one and e1, e2 the edges leaving it (large split triangles are mostly
+// halves of rectangles, cut along their legs: with the legs as axes the bounds of a cell's part are the cell itself).
+// Seven bits per bound, rounded outwards: (origin vertex + 1) << 28 | u0 | v0 << 7 | u1 << 14 | v1 << 21; never 0, which
+// marks a triangle entered whole.  The weights of a point do not change under the affine object-to-world map, so a refit
+// can bound the part again after any transform edit: the parts of a triangle cover it in (u, v) wherever its vertices move.
+__device__ uint32_t part_code(v3 a, v3 b, v3 c, const float (*poly)[3], int np)
+{
+    const v3 p[3] = {a, b, c};
+    int org = 0;
+    float best = __builtin_inff();
+    for (int i = 0; i < 3; i++) {
+        const v3 ea = p[(i + 1) % 3] - p[i], eb = p[(i + 2) % 3] - p[i];
+        const float d = dot(ea, eb), score = d * d / (dot(ea, ea) * dot(eb, eb));     // cos^2 of the angle at vertex i
+        if (score < best) { best = score; org = i; }
+    }
+    const v3 o = p[org], e1 = p[(org + 1) % 3] - o, e2 = p[(org + 2) % 3] - o, n = cross(e1, e2);
+    const float nn = dot(n, n);
+    float u0 = 1.0f, u1 = 0.0f, v0 = 1.0f, v1 = 0.0f;
+    for (int i = 0; i < np; i++) {
+        const v3 d = V3(poly[i][0], poly[i][1], poly[i][2]) - o;
+        const float u = dot(cross(d, e2), n) / nn, v = dot(cross(e1, d), n) / nn;
+        u0 = fminf(u0, u); u1 = fmaxf(u1, u); v0 = fminf(v0, v); v1 = fmaxf(v1, v);
+    }
+    const uint32_t whole = ((uint32_t)(org + 1) << 28) | (127u << 14) | (127u << 21);
+    if (!(u0 <= u1) || !(v0 <= v1)) return whole;                  // a degenerate triangle (NaN weights): the whole range
+    const float eps = 1e-5f;                                       // rounding of the weights themselves
+    const int q0 = (int)floorf((u0 - eps) * 127.0f), q1 = (int)ceilf((u1 + eps) * 127.0f);
+    const int r0 = (int)floorf((v0 - eps) * 127.0f), r1 = (int)ceilf((v1 + eps) * 127.0f);
+    return ((uint32_t)(org + 1) << 28) | (uint32_t)min(max(q0, 0), 127) | ((uint32_t)min(max(r0, 0), 127) << 7) |
+           ((uint32_t)min(max(q1, 0), 127) << 14) | ((uint32_t)min(max(r1, 0), 127) << 21);
+}
+
+// bounds of the part of triangle (a, b, c) inside the box [clo, chi]; false if there is none.  code (may be null): part_code of the part
+__device__ bool clip_bounds(v3 a, v3 b, v3 c, const float* clo, const float* chi, float* olo, float* ohi, uint32_t* code = nullptr)
 {
     float px[2][10][3];
     int np = 3, cur = 0;
@@ -188,6 +238,7 @@ __device__ bool clip_bounds(v3 a, v3 b, v3 c, const float* clo, const float* chi
         }
     // the clipped vertices carry rounding; the part can neither leave the cell nor the triangle's own box
     for (int k = 0; k < 3; k++) { olo[k] = fmaxf(olo[k], clo[k]); ohi[k] = fminf(ohi[k], chi[k]); }
+    if (code) *code = part_code(a, b, c, px[cur], np);
     return true;
 }
 
@@ -249,6 +300,7 @@ __global__ void __launch_bounds__(64) k_split_cells(uint32_t ncand, const uint32
             const int ci = c0 + (int)lane;
             bool hit = false;
             float olo[3], ohi[3];
+            uint32_t code = 0;
             if (ci < total) {
                 const int idx[3] = {ci % nc[0], (ci / nc[0]) % nc[1], ci / (nc[0] * nc[1])};
                 float clo[3], chi[3];
@@ -256,12 +308,14 @@ __global__ void __launch_bounds__(64) k_split_cells(uint32_t ncand, const uint32
                     clo[k] = lo[k] + (float)idx[k] * cell;
                     chi[k] = idx[k] + 1 == nc[k] ? hi[k] : lo[k] + (float)(idx[k] + 1) * cell;
                 }
-                hit = clip_bounds(a, b, c, clo, chi, olo, ohi);
+                hit = clip_bounds(a, b, c, clo, chi, olo, ohi, WRITE ? &code : nullptr);
             }
             const unsigned long long m = __ballot(hit);
             if (WRITE && hit) {
                 const uint32_t pos = w + found + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                out_tris[pos] = t;
+                TriRec part = t;
+                part.pad = code;
+                out_tris[pos] = part;
                 out_lo[pos] = make_float4(olo[0], olo[1], olo[2], 0.0f);
                 out_hi[pos] = make_float4(ohi[0], ohi[1], ohi[2], 0.0f);
             }
@@ -1515,7 +1569,7 @@ int refit_accel(pt_ctx* ctx)
     PT_SYNC(ctx);
     if (!ctx->accel_built) return set_error(ctx, PT_ERR_INVALID, "refit: no hierarchy has been built");
     hipStream_t st = ctx->stream;
-    const uint32_t n = ctx->num_refs;     // every reference of a split triangle gets the whole triangle's box back: correct, less tight
+    const uint32_t n = ctx->num_refs;     // a reference to a part of a split triangle is bounded again from the part's barycentric bounds
     pt_accel_stats& stats = ctx->accel_stats;
     if (n == 0) return PT_OK;
     EventPair ev;        // destroyed on every way out

@@ -33,12 +33,15 @@ struct alignas(128) Node8 {
 #define PT_MAX_CHAINS 16    // independent pipelines a frame can be split into (a divisor of PT_SHARDS)
 #endif
 
-// world-space triangle, 48 bytes, in leaf order: (v0, submesh) (v1, prim) (v2, 0).  Inside a leaf the records are in
-// ascending (submesh, prim) order: the traversal's triangle phase settles hits at equal distance by position in the leaf
+// world-space triangle, 48 bytes, in leaf order: (v0, submesh) (v1, prim) (v2, part).  Inside a leaf the records are in
+// ascending (submesh, prim) order: the traversal's triangle phase settles hits at equal distance by position in the leaf.
+// part = 0 for a triangle entered whole; for a reference to a part of a split triangle, the bounds of the part's
+// weights in the frame of the triangle's squarest corner (origin vertex + 1 in bits 28-31, four 7-bit bounds below), from
+// which a refit bounds the part again
 struct alignas(16) TriRec {
     float v0x, v0y, v0z; uint32_t submesh;
     float v1x, v1y, v1z; uint32_t prim;
-    float v2x, v2y, v2z; uint32_t pad;
+    float v2x, v2y, v2z; uint32_t pad;      // the part code
 };
 
 #ifndef PT_MAX_BATCH

@@ -663,10 +663,66 @@ def test_split_triangles_change_no_result(backend):
     ids = tris[:, 3].astype(np.uint64) << np.uint64(32) | tris[:, 7].astype(np.uint64)
     uniq, counts = np.unique(ids, return_counts=True)
     assert len(uniq) == st.num_triangles and counts.max() <= 64 and (counts > 1).sum() > 50
-    # all references of a triangle carry the same record
+    # all references of a triangle carry the same vertices and ids; word 11 is 0 for a triangle entered whole, and for a
+    # reference to a part the bounds of the part's weights: (origin vertex + 1) << 28 | u0 | v0 << 7 | u1 << 14 | v1 << 21
     order = np.argsort(ids, kind="stable")
     same = ids[order][1:] == ids[order][:-1]
-    assert np.array_equal(tris[order][1:][same], tris[order][:-1][same])
+    assert np.array_equal(tris[order][1:][same][:, :11], tris[order][:-1][same][:, :11])
+    split_ids = uniq[counts > 1]
+    is_part = np.isin(ids, split_ids)
+    code = tris[:, 11]
+    assert (code[~is_part] == 0).all() and (code[is_part] != 0).all()
+    u0, v0, u1, v1 = code & 127, (code >> 7) & 127, (code >> 14) & 127, (code >> 21) & 127
+    assert (u0[is_part] <= u1[is_part]).all() and (v0[is_part] <= v1[is_part]).all() and ((code[is_part] >> 28) - 1 <= 2).all()
+    assert ((u1 - u0)[is_part].astype(np.int64) * (v1 - v0)[is_part] < 127 * 127 // 4).mean() > 0.95     # parts, not the whole range
+
+
+def test_refit_of_split_triangles_under_new_transforms(backend):
+    """A refit keeps the references of split triangles tight: each is bounded again from the barycentric bounds of its part,
+    which no affine transform changes.  Unchanged transforms: the refitted hierarchy costs little more than the built one and
+    less than the hierarchy without splitting.  Then a third of the submeshes is rotated, sheared and moved: hits after the
+    refit equal the oracle's brute-force loop over the moved triangles."""
+    import copy
+    sc = procedural.sponza_class(detail=0.05, layout="sponza", textures=True)
+    backend.scene_upload(sc)
+    whole = backend.build_accel(2).sah_cost
+    built = backend.build_accel(0)
+    assert built.num_references > built.num_triangles
+    built_cost = built.sah_cost
+    same = backend.update_transforms(sc.xforms, flags=0x100)
+    assert same.sah_cost < built_cost * 1.1 and same.sah_cost < 0.5 * (built_cost + whole), (built_cost, same.sah_cost, whole)
+    rng = np.random.default_rng(5)
+    xf = sc.xforms.copy().reshape(-1, 3, 4)
+    for i in range(0, len(xf), 3):
+        a = rng.uniform(-0.3, 0.3)
+        rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        shear = np.eye(3)
+        shear[0, 1] = rng.uniform(-0.2, 0.2)
+        m = rot @ shear
+        xf[i, :, :3] = (m @ xf[i, :, :3].astype(np.float64)).astype(np.float32)
+        xf[i, :, 3] = (m @ xf[i, :, 3].astype(np.float64) + rng.uniform(-0.5, 0.5, 3)).astype(np.float32)
+    moved = copy.copy(sc)
+    moved.xforms = np.ascontiguousarray(xf.reshape(-1, 12))
+    st = backend.update_transforms(moved.xforms, flags=0x100)
+    assert st.num_references == built.num_references
+    rays = random_rays(rng, 20000, [-14, 0.3, -8], [14, 10.5, 8])
+    tri = _world_triangles(moved)
+    e = tri.max(1) - tri.min(1)
+    big = np.argsort(-(e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0]))[:400]
+    pick = rng.choice(big, 6000)
+    w = rng.dirichlet((1, 1, 1), len(pick))
+    target = (tri[pick] * w[:, :, None]).sum(1)
+    origin = rng.uniform([-14, 0.3, -8], [14, 10.5, 8], (len(pick), 3))
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aimed = np.zeros((len(pick), 8), np.float32)
+    aimed[:, 0:3], aimed[:, 3], aimed[:, 4:7], aimed[:, 7] = origin, 1e-4, d, 1e27
+    rays = np.concatenate([aimed, rays])
+    got, _ = backend.debug_intersect(rays)
+    o = oracle_lib.Oracle(moved)
+    assert np.array_equal(got, o.intersect(rays, use_bvh=False))
+    assert (got[:len(pick), 3] != M32).mean() > 0.9
+    o.close()
 
 
 def test_split_triangles_frames_bit_exact(backend):
