@@ -160,7 +160,7 @@ def make_workload(name, width, height, detail=1.0):
 class Case:
     """One workload resident on one GPU: scene, hierarchy, environment, images, camera and parameters set."""
 
-    def __init__(self, args, name, width, height, local_rank, device, gltf=None):
+    def __init__(self, args, name, width, height, local_rank, device, gltf=None, precision=None):
         from pathtracer_amd import distributed as ptdist
         from pathtracer_amd.backend import Backend
         from pathtracer_amd.scene import Params
@@ -182,8 +182,9 @@ class Case:
             self.sky_text = "Preetham sky (turbidity %g, azimuth %g, inclination %g) as a %d-texel cube x10" % SKY
         else:
             self.sky_text = "constant white sky x10"
-        if args.precision:
-            b.set_precision(args.precision)
+        self.precision = args.precision if precision is None else precision
+        if self.precision:
+            b.set_precision(self.precision)
         self.r = ptdist.GpuRenderer(b, width, height, device)
         b.set_camera(self.cam)
         b.set_params(self.params)
@@ -195,7 +196,9 @@ class Case:
         self.b.set_batch(batch if batch > 0 else max(1, min(8, (steps + nbatches - 1) // nbatches)))
 
     def describe(self, bounces):
-        return "%s, %dx%d, 1 spp/frame, %d bounces, no Russian roulette, %s; %s" % (self.name, self.width, self.height, bounces, self.sky_text, self.text)
+        return "%s, %dx%d, 1 spp/frame, %d bounces, no Russian roulette, %s%s; %s" % (
+            self.name, self.width, self.height, bounces, self.sky_text,
+            ", shading arithmetic within a stated tolerance (pt_set_precision 1)" if self.precision else "", self.text)
 
     def hierarchy(self):
         a = self.accel
@@ -211,11 +214,11 @@ class Case:
         self.b.close()
 
 
-def load_counters(workload, args, width, height):
+def load_counters(workload, args, width, height, precision):
     """Per-ray counters of the two hot kernels from the committed rocprofv3 --pmc passes over this workload, or (None, why)."""
     cpath = os.path.join(ROOT, "profiles", "counters_per_ray_%s.json" % workload)
     # per-ray figures carry over to other image sizes of the same scene and camera (the rays are distributed alike)
-    if (args.bounces, args.detail, args.build_flags, args.sky, args.precision) != (8, 1.0, 0, "preetham", 0) or abs(width * 9 - height * 16) > 16:
+    if (args.bounces, args.detail, args.build_flags, args.sky, precision) != (8, 1.0, 0, "preetham", 0) or abs(width * 9 - height * 16) > 16:
         return None, None, "non-default parameters"
     try:
         ctr = json.load(open(cpath))
@@ -245,7 +248,7 @@ def profile_case(case, frames, args, timed_rays_per_s):
     alg_bytes = count_rays * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES
     alg_gbs = alg_bytes / (ext_busy_ms * 1e-3) / 1e9 if ext_busy_ms > 0 else 0.0
     rays_per_launch = count_rays / max(1, ext_launches)
-    ctr, cpath, why = load_counters(case.name, args, case.width, case.height)
+    ctr, cpath, why = load_counters(case.name, args, case.width, case.height, case.precision)
     stale = None
     if ctr is not None:
         stale = ctr.get("csrc_sha16") != csrc_sha16()
@@ -466,12 +469,13 @@ def main():
     # ---- the other workloads, timed briefly (N = 1): every BASELINE configuration gets a driver-timed figure ----
     nother = 16 if args.others < 0 else args.others
     if rank == 0 and world == 1 and nother > 0 and not args.gltf:
-        cases = [("sponza_class", 1920, 1080), ("bistro_class", 1920, 1080), (args.workload, 3840, 2160), ("cornell", 1920, 1080)]
+        cases = [("sponza_class", 1920, 1080, None), ("bistro_class", 1920, 1080, None), (args.workload, 3840, 2160, None), ("cornell", 1920, 1080, None),
+                 (args.workload, args.width, args.height, 1 - args.precision)]      # the headline again with the other shading arithmetic
         others = []
-        for name, w, h in cases:
-            if (name, w, h) == (args.workload, args.width, args.height):
+        for name, w, h, prec in cases:
+            if (name, w, h, prec) == (args.workload, args.width, args.height, None):
                 continue
-            c = Case(args, name, w, h, local_rank, device)
+            c = Case(args, name, w, h, local_rank, device, precision=prec)
             d, n, _, fr = timed(c, nother, 4)
             nanpx = c.nan_pixels()
             rl = profile_case(c, fr[:8], args, n / d)

@@ -475,19 +475,25 @@ int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height)
     size_t tiles = (size_t)((width + 7) / 8) * ((height + 7) / 8);
     ctx->shard_cap = (uint32_t)((tiles + PT_SHARDS - 1) / PT_SHARDS) * 64u * PT_MAX_BATCH;
     size_t slots = (size_t)ctx->shard_cap * PT_SHARDS;
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_image_own, n * 16));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_accum_own, n * 16));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_primary, n * 8));
-    for (int i = 0; i < 2; i++) {
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_rayO[i], slots * 16));
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_rayD[i], slots * 16));
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_stA[i], slots * 16));
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_stB[i], slots * 16));
+    // everything a frame batch needs is reserved here: images (40 B per pixel) and, for PT_MAX_BATCH frames in flight, two ray queues,
+    // two path-state queues, hit records and the per-path colours (about 1.4 KB per pixel: 2.9 GB at 1920x1080, 11.7 GB at 3840x2160)
+    const size_t total_bytes = n * (16 + 16 + 8) + slots * (4 * 2 * 16 + 16 + 4) + n * PT_MAX_BATCH * 32;
+    struct { void** p; size_t bytes; } wanted[] = {
+        {(void**)&ctx->d_image_own, n * 16}, {(void**)&ctx->d_accum_own, n * 16}, {(void**)&ctx->d_primary, n * 8},
+        {(void**)&ctx->d_rayO[0], slots * 16}, {(void**)&ctx->d_rayD[0], slots * 16}, {(void**)&ctx->d_stA[0], slots * 16}, {(void**)&ctx->d_stB[0], slots * 16},
+        {(void**)&ctx->d_rayO[1], slots * 16}, {(void**)&ctx->d_rayD[1], slots * 16}, {(void**)&ctx->d_stA[1], slots * 16}, {(void**)&ctx->d_stB[1], slots * 16},
+        {(void**)&ctx->d_hits, slots * 16}, {(void**)&ctx->d_hit_det, slots * 4},
+        {(void**)&ctx->d_stC, n * PT_MAX_BATCH * 16}, {(void**)&ctx->d_partial, n * PT_MAX_BATCH * 16}};
+    for (auto& w : wanted) {
+        hipError_t e = hipMalloc(w.p, w.bytes);
+        if (e != hipSuccess) {
+            free_images(ctx);
+            (void)hipGetLastError();
+            return set_error(ctx, PT_ERR_HIP, "pt_resize: " + std::to_string(width) + "x" + std::to_string(height) + " needs " + std::to_string(total_bytes >> 20) +
+                             " MiB of device memory for images, ray queues and path state (about 1.4 KB per pixel, reserved up front for batches of " +
+                             std::to_string(PT_MAX_BATCH) + " frames); hipMalloc of " + std::to_string(w.bytes >> 20) + " MiB failed: " + hipGetErrorString(e));
+        }
     }
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_hits, slots * 16));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_hit_det, slots * 4));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stC, n * PT_MAX_BATCH * 16));
-    PT_HIP(ctx, hipMalloc((void**)&ctx->d_partial, n * PT_MAX_BATCH * 16));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_image_own, 0, n * 16, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_accum_own, 0, n * 16, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, n * 8, ctx->stream));
