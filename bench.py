@@ -12,8 +12,8 @@ max-over-ranks wall time, inputs resident in HBM.
 The headline workload is the closest stand-in this repository has for the reference's textured Crytek Sponza
 (whose geometry file is absent from the reference checkout): `sponza_like`, an atrium with large wall / floor quads, thin
 diagonal parts, 16 textures and split triangles, lit through the open roof by the reference's Preetham sky
-(RayTracingLayer.h:88: turbidity 3.14, azimuth 0, inclination 0) as a 2048-texel-per-face cube, so that a miss pays a real
-environment lookup (RayGen.glsl:132).  At N = 1 the other workloads are timed briefly after the headline and
+(RayTracingLayer.h:88: turbidity 3.14, azimuth 0, inclination 0) as a 2048-texel-per-face cube (texels on and below the
+horizon, where that shader has no values, mirrored from above), so that a miss pays a real environment lookup (RayGen.glsl:132).  At N = 1 the other workloads are timed briefly after the headline and
 printed on the same JSON line as `other_workloads`: the uniformly tessellated Sponza-class atrium, the 3 M-triangle
 Bistro-class street (hierarchy build time + rays per second), the headline scene at 3840x2160 and the Cornell box.
 
@@ -96,13 +96,17 @@ def lavapipe_probe():
     return "unavailable: " + "; ".join(missing)
 
 
+KERNEL_SOURCES = ["trace.hip", "pt_traverse.h", "pt_shade.inc", "pt_bsdf.inc", "pt_fast.h", "pt_math.h", "pt_vec.inc", "pt_types.h", "bvh_build.hip"]
+
+
 def csrc_sha16():
-    """Hash of the kernel sources: the per-ray counters under profiles/ are properties of this code."""
+    """Hash of the sources that decide the instruction streams of the two hot kernels and the shape of the hierarchy (not the
+    host-side API and the image passes): the per-ray counters under profiles/ are properties of this code."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "pathtracer_amd", "csrc")
-    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc"))):
-        h.update(os.path.basename(p).encode())
-        h.update(open(p, "rb").read())
+    for name in KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -174,12 +178,14 @@ class Case:
         b.scene_upload(self.scene)
         self.first_build_ms = b.build_accel(args.build_flags).build_ms     # includes the allocator's first touches
         self.accel = b.build_accel(args.build_flags)                       # the same build again: its steady-state time
-        # the Cornell box opens sideways, and the reference's Preetham shader has no values below the horizon (B / cos(theta) at
-        # theta = pi / 2: NaN texels), so that scene keeps the constant sky; the atria and the street see the sky from below
-        self.sky = "white" if name == "cornell" else args.sky
+        self.sky = args.sky
         if self.sky == "preetham":
+            # the reference's sky pass on the GPU; its shader has no values on and below the horizon (NaN texels, which would turn
+            # every pixel a path leaves that way NaN for good), so those texels take the sky's value mirrored at the horizon
+            from pathtracer_amd import procedural
             b.env_preetham(*SKY)
-            self.sky_text = "Preetham sky (turbidity %g, azimuth %g, inclination %g) as a %d-texel cube x10" % SKY
+            b.env_upload(procedural.sky_mirrored_below_the_horizon(b.read_env()))
+            self.sky_text = "Preetham sky (turbidity %g, azimuth %g, inclination %g) as a %d-texel cube, mirrored below the horizon, x10" % SKY
         else:
             self.sky_text = "constant white sky x10"
         self.precision = args.precision if precision is None else precision
@@ -314,7 +320,8 @@ def cpu_baseline(case, args, steps):
     threads, nproc, aff = host_threads()
     scene = case.scene
     if case.sky == "preetham":
-        scene.env = oracle_lib.preetham_sky(*SKY)      # the oracle's own sky pass (bit-equal to the GPU's, tests/test_gpu_parity.py)
+        from pathtracer_amd import procedural
+        scene.env = procedural.sky_mirrored_below_the_horizon(oracle_lib.preetham_sky(*SKY))      # the oracle's own sky pass (bit-equal to the GPU's, tests/test_gpu_parity.py)
     o = oracle_lib.Oracle(scene, threads=threads)
     o.resize(case.width, case.height)
     o.set_camera(case.cam)

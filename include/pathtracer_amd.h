@@ -187,12 +187,15 @@ int pt_update_transforms(pt_ctx* ctx, const float* submesh_xforms, uint32_t num_
 int pt_postprocess(pt_ctx* ctx, float exposure);
 int pt_read_postprocessed(pt_ctx* ctx, uint8_t* rgba8);      /* width*height*4 bytes */
 void* pt_device_postprocessed(pt_ctx* ctx);
-/* Environment sources for binding 10.  Both replace the cube map set by pt_scene_upload (call them after it).
+/* Environment sources for binding 10.  All replace the cube map set by pt_scene_upload (call them after it).
+ * pt_env_upload: a cube the caller made, 6*face_size*face_size*4 floats, faces +X -X +Y -Y +Z -Z (the descriptor write of
+ *   m_RadianceMap, RayTracingLayer.cpp:258, without re-uploading the scene).
  * pt_env_from_equirect: what the engine's TextureCube does with its .hdr radiance image (RayTracingLayer.cpp:50-54,
  *   EquirectangularToCubeMap.glsl:11-40): rgba = width*height*4 floats, row 0 = top; the cube holds binary16 values.
  * pt_env_preetham: the Preetham sky pass (RayTracingLayer.cpp:56-76,366-381, PreethamSky.glsl:17-146; defaults
  *   turbidity 3.14, azimuth 0, inclination 0 at RayTracingLayer.h:88, 2048 texels per face).
  * pt_read_env: the current cube, 6*n*n*4 floats, faces +X -X +Y -Y +Z -Z; rgba may be NULL to query n only. */
+int pt_env_upload(pt_ctx* ctx, const float* rgba, uint32_t face_size);
 int pt_env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t width, uint32_t height, uint32_t face_size);
 int pt_env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclination, uint32_t face_size);
 int pt_read_env(pt_ctx* ctx, float* rgba, uint32_t* face_size);

@@ -17,7 +17,7 @@ EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_last_warning", "pt_hardware_queues", "pt_default_params", "pt_scene_upload", "pt_build_accel",
     "pt_update_materials", "pt_update_transforms", "pt_resize", "pt_bind_images", "pt_set_camera", "pt_set_params", "pt_set_precision", "pt_trace", "pt_sync",
     "pt_read_image", "pt_read_accum", "pt_write_accum", "pt_resolve", "pt_read_primary_ids", "pt_ray_count",
-    "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
+    "pt_postprocess", "pt_read_postprocessed", "pt_device_postprocessed", "pt_env_upload", "pt_env_from_equirect", "pt_env_preetham", "pt_read_env",
     "pt_set_chains", "pt_set_batch", "pt_set_profiling", "pt_last_trace_timing", "pt_stream", "pt_wait_stream", "pt_reduce_accum", "pt_device_image", "pt_device_accum",
     "pt_debug_intersect", "pt_intersect_noalloc", "pt_debug_math", "pt_debug_disney_sample", "pt_debug_disney_eval", "pt_debug_read_bvh",
 ]
@@ -85,6 +85,7 @@ def load_library():
     lib.pt_postprocess.argtypes = [vp, C.c_float]
     lib.pt_read_postprocessed.argtypes = [vp, C.POINTER(C.c_uint8)]
     lib.pt_env_from_equirect.argtypes = [vp, fp, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.pt_env_upload.argtypes = [vp, fp, C.c_uint32]
     lib.pt_env_preetham.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_uint32]
     lib.pt_read_env.argtypes = [vp, fp, up]
     lib.pt_set_chains.argtypes = [vp, C.c_uint32]
@@ -232,6 +233,12 @@ class Backend:
         rgba = np.ascontiguousarray(rgba, np.float32)
         h, w = rgba.shape[:2]
         self._check(self.lib.pt_env_from_equirect(self.h, _fp(rgba), w, h, int(face_size)))
+
+    def env_upload(self, cube):
+        """cube: (6, n, n, 4) float32 radiance, faces +X -X +Y -Y +Z -Z; replaces the environment of the uploaded scene."""
+        cube = np.ascontiguousarray(cube, np.float32)
+        assert cube.ndim == 4 and cube.shape[0] == 6 and cube.shape[1] == cube.shape[2] and cube.shape[3] == 4
+        self._check(self.lib.pt_env_upload(self.h, _fp(cube), cube.shape[1]))
 
     def env_preetham(self, turbidity=3.14, azimuth=0.0, inclination=0.0, face_size=2048):
         self._check(self.lib.pt_env_preetham(self.h, float(turbidity), float(azimuth), float(inclination), int(face_size)))

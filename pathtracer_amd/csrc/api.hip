@@ -699,6 +699,15 @@ int pt_env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclinati
     return env_preetham(ctx, turbidity, azimuth, inclination, face_size);
 }
 
+int pt_env_upload(pt_ctx* ctx, const float* rgba, uint32_t face_size)
+{
+    if (!ctx || !rgba) return PT_ERR_INVALID;
+    int rc = check_env_args(ctx, face_size);
+    if (rc) return rc;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return env_upload(ctx, rgba, face_size);
+}
+
 int pt_read_env(pt_ctx* ctx, float* rgba, uint32_t* face_size)
 {
     if (!ctx) return PT_ERR_INVALID;

@@ -214,6 +214,15 @@ int env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t w, uint32_t h, ui
     return PT_OK;
 }
 
+int env_upload(pt_ctx* ctx, const float* rgba, uint32_t n)
+{
+    int rc = replace_env(ctx, n);
+    if (rc) return rc;
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_env, rgba, (size_t)6 * n * n * 16, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the host array may go away after return
+    return PT_OK;
+}
+
 int env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclination, uint32_t n)
 {
     int rc = replace_env(ctx, n);

@@ -131,6 +131,7 @@ int launch_resolve(pt_ctx* ctx);
 int launch_postprocess(pt_ctx* ctx, float exposure);
 int env_from_equirect(pt_ctx* ctx, const float* rgba, uint32_t w, uint32_t h, uint32_t face_size);
 int env_preetham(pt_ctx* ctx, float turbidity, float azimuth, float inclination, uint32_t face_size);
+int env_upload(pt_ctx* ctx, const float* rgba, uint32_t face_size);
 int sync_streams(pt_ctx* ctx);     // host waits for every chain
 int check_fault(pt_ctx* ctx);      // PT_ERR_TRAVERSAL if a traversal wave reached its iteration bound since the last check
 int collect_slot(pt_ctx* ctx, pt_prof_slot& slot);   // waits for that frame, adds it to the timing window

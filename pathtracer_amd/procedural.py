@@ -454,3 +454,27 @@ def bistro_camera(width, height):
     from . import camera
     view = camera.look_at((-50.0, 3.2, 1.5), (0.0, 5.0, -1.0))
     return camera.camera_buffer(view, camera.perspective(60.0, width / height, 0.05, 500.0))
+
+
+def sky_mirrored_below_the_horizon(cube):
+    """The reference's Preetham sky pass (PreethamSky.glsl) only has values above the horizon: its Perez term divides by
+    cos(theta), which is 0 on the horizon and clamped there below it, so the lower half of the cube is NaN or infinite, and one
+    such texel under a path turns its pixel NaN for good.  For a workload whose rays can leave downwards or along the horizon,
+    this fills every non-finite texel with the sky's value in the direction mirrored at the horizon plane (y -> -y).
+    cube: (6, n, n, 4), faces +X -X +Y -Y +Z -Z with rows running along -y on the four side faces; returns a new array."""
+    cube = np.array(cube, np.float32, copy=True)
+    for f in (0, 1, 4, 5):
+        bad = ~np.isfinite(cube[f]).all(-1)
+        cube[f][bad] = cube[f][::-1][bad]
+    bad = ~np.isfinite(cube[3]).all(-1)
+    cube[3][bad] = cube[2][::-1][bad]        # -Y from +Y: same s = x, t = -z against t = z
+    # what is still not finite (the horizon row itself, if any) takes the nearest finite row above it
+    for f in (0, 1, 4, 5):
+        for _ in range(4):
+            bad = ~np.isfinite(cube[f]).all(-1)
+            if not bad.any():
+                break
+            up = np.roll(cube[f], 1, axis=0)
+            cube[f][bad] = up[bad]
+    cube[~np.isfinite(cube).all(-1)] = (0.0, 0.0, 0.0, 1.0)
+    return cube
