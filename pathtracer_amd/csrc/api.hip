@@ -110,7 +110,7 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
     slot.pending = false;
     pt_trace_timing& t = ctx->timing;
     const uint32_t R = slot.rounds, C = slot.chains, spc = PT_SHARDS / C;
-    const size_t chain_words = pt_chain_words(R, spc);
+    const size_t chain_words = pt_chain_words(slot.layout_rounds, spc);
     for (uint32_t c = 0; c < C; c++) PT_HIP(ctx, hipEventSynchronize(slot.ev[c][2 + 2 * R]));
     for (uint32_t c = 0; c < C; c++) {
         std::vector<hipEvent_t>& ev = slot.ev[c];
@@ -133,7 +133,7 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
             }
             t.rays += queued;
         }
-        t.rays -= slot.h_counts[c * chain_words + (size_t)2 * (R + 1) * spc];     // deferred rays were queued twice
+        t.rays -= slot.h_counts[c * chain_words + (size_t)2 * (slot.layout_rounds + 1) * spc];     // deferred rays were queued twice
         float a = 0.0f, b = 0.0f;
         PT_HIP(ctx, hipEventElapsedTime(&a, ctx->prof_ref, ev[0]));
         PT_HIP(ctx, hipEventElapsedTime(&b, ctx->prof_ref, ev[2 + 2 * R]));
@@ -269,7 +269,7 @@ int pt_create(int device_ordinal, pt_ctx** out)
     }
     const uint32_t hwq = ctx->hw_queues;
     ctx->chains = hwq >= 16 ? 16u : (hwq >= 8 ? 8u : 4u);
-    if (const char* e = getenv("PT_DEFER")) { int v = atoi(e); ctx->defer_rounds = v < 0 ? 0u : (v > 8 ? 8u : (uint32_t)v); }
+    if (const char* e = getenv("PT_DEFER")) { int v = atoi(e); ctx->defer_rounds = v < 0 ? 0u : (v > 8 ? 8u : (uint32_t)v); ctx->defer_forced = true; }
     if (const char* e = getenv("PT_CHAINS")) {
         uint32_t c = (uint32_t)atoi(e);
         if (c >= 1 && c <= PT_MAX_CHAINS && PT_SHARDS % c == 0) ctx->chains = c;

@@ -13,6 +13,7 @@ struct pt_prof_slot {
     uint32_t* h_counts = nullptr;     // pinned copy of the frame's queue sizes
     size_t h_words = 0;
     uint32_t rounds = 0, chains = 0;
+    uint32_t layout_rounds = 0;       // rounds the counter block is laid out for (>= rounds)
     bool pending = false;
 };
 #define PT_PROF_SLOTS 4
@@ -91,6 +92,7 @@ struct pt_ctx {
     uint32_t* d_counts = nullptr;   // per chain: rounds + 1 rows of queue sizes (one per shard of the chain), then as many rows of fetch cursors
     uint32_t counts_cap = 0;
     uint32_t defer_rounds = 2;      // rounds a path may fall behind because its ray was suspended at the tail of a launch (PT_DEFER; 0: off)
+    bool defer_forced = false;      // PT_DEFER was set: every batch suspends (or none); otherwise launch_trace decides per batch
     uint32_t* d_suspend = nullptr;  // suspended traversals, [chain][2][shard of the chain][slot][16 + 2 * stack_entries]
     size_t suspend_words = 0;
     uint2* d_spill = nullptr;       // traversal stack spill area, [chain][wave][entry][lane]

@@ -439,8 +439,19 @@ int launch_trace(pt_ctx* ctx)
     ctx->pending.clear();          // before anything below synchronises, which would flush again
     const pt_params& pp = ctx->params;
     uint32_t npix = ctx->width * ctx->height;
-    // more rounds than the longest path needs: a path falls a round behind each time its ray is suspended
-    const uint32_t rounds = pp.spp_per_frame * pp.max_bounces + ctx->defer_rounds;
+    // Suspension of the last rays of a traversal launch (pt_traverse.h) pays when a launch has little to overlap with: with one
+    // or two frames per batch it is worth +2 ... +8 % on deep hierarchies; with the launches of four or more frames in
+    // flight on every chain the tail of a launch hides behind the other chains' work anyway, and the suspension records, the
+    // two extra rounds and the larger kernel variant cost 1 ... 7 %.  A shallow hierarchy (a ray takes two or three node
+    // steps) loses either way.  PT_DEFER in the environment overrides the choice for every batch.
+    static const uint32_t defer_max_batch = getenv("PT_DEFER_MAX_BATCH") ? (uint32_t)atoi(getenv("PT_DEFER_MAX_BATCH")) : 2u;
+    const uint32_t defer = ctx->defer_forced ? ctx->defer_rounds
+                                             : ((nframes <= defer_max_batch && ctx->accel_stats.sah_cost >= 20.0f) ? ctx->defer_rounds : 0u);
+    // more rounds than the longest path needs: a path falls a round behind each time its ray is suspended.  The counters
+    // are laid out for the most rounds any batch can take, so that batches with and without suspension that follow each other
+    // on a chain use the same block
+    const uint32_t rounds = pp.spp_per_frame * pp.max_bounces + defer;
+    const uint32_t layout_rounds = pp.spp_per_frame * pp.max_bounces + ctx->defer_rounds;
     TraceParams P;
     P.width = ctx->width; P.height = ctx->height;
     P.spp = pp.spp_per_frame; P.max_bounces = pp.max_bounces; P.rr_depth = pp.rr_depth;
@@ -454,7 +465,7 @@ int launch_trace(pt_ctx* ctx)
     const uint32_t chains = ctx->chains;
     const uint32_t spc = PT_SHARDS / chains;                  // shards per chain
     const size_t need_events = 2 + 2 * (size_t)rounds + 1;
-    const size_t chain_words = pt_chain_words(rounds, spc);        // queue sizes, fetch cursors, deferred-ray count
+    const size_t chain_words = pt_chain_words(layout_rounds, spc);        // queue sizes, fetch cursors, deferred-ray count
     pt_prof_slot* slot = nullptr;
     bool window_start = false;
     if (prof) {
@@ -477,6 +488,7 @@ int launch_trace(pt_ctx* ctx)
             slot->h_words = chain_words * chains;
         }
         slot->rounds = rounds;
+        slot->layout_rounds = layout_rounds;
         slot->chains = chains;
         if (!ctx->window_open) {
             if (!ctx->prof_ref) PT_HIP(ctx, hipEventCreate(&ctx->prof_ref));
@@ -522,7 +534,7 @@ int launch_trace(pt_ctx* ctx)
     const uint32_t susp_words = PT_SUSPEND_STATE_WORDS + 2u * ctx->stack_entries;
     {
         size_t need = (size_t)chains * 2 * spc * susp_cap * susp_words;
-        if (ctx->defer_rounds && need > ctx->suspend_words) {
+        if (defer && need > ctx->suspend_words) {
             PT_SYNC(ctx);
             if (ctx->d_suspend) (void)hipFree(ctx->d_suspend);
             ctx->d_suspend = nullptr;
@@ -565,8 +577,8 @@ int launch_trace(pt_ctx* ctx)
         size_t ev = 0;
         auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(slot->ev[c][ev++], st) : hipSuccess; };
         uint32_t* counts = ctx->d_counts + c * chain_words;
-        uint32_t* cursors = counts + (size_t)(rounds + 1) * spc;
-        uint32_t* deferred = cursors + (size_t)(rounds + 1) * spc;
+        uint32_t* cursors = counts + (size_t)(layout_rounds + 1) * spc;
+        uint32_t* deferred = cursors + (size_t)(layout_rounds + 1) * spc;
         k_set_views<<<1, 64, 0, st>>>(views, ctx->d_views + c * PT_MAX_BATCH);
         // dry: only collects the launch arguments into `key`
         auto issue = [&](bool dry, std::string* key) -> int {
@@ -607,8 +619,8 @@ int launch_trace(pt_ctx* ctx)
                 memset(&ea, 0, sizeof(ea));
                 ea.tmin = P.tmin; ea.tmax = P.tmax;
                 ea.counts = counts + r * spc; ea.cursors = cursors + r * spc;
-                ea.next_counts = (ctx->defer_rounds && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
-                ea.max_lag = ctx->defer_rounds;
+                ea.next_counts = (defer && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
+                ea.max_lag = defer;
                 ea.susp_cap = susp_cap;
                 ea.susp_words = susp_words;
                 ea.stack_entries = ctx->stack_entries;
