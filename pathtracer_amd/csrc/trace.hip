@@ -512,8 +512,10 @@ int launch_trace(pt_ctx* ctx)
     // slower on a mid-sized and on a large scene, 128 loses 1-3 %, 192 loses 5 %)
     static const uint32_t waves_override = getenv("PT_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_EXT_WAVES_PER_CU")) : 0u;
     // a shallow scene (surface-area cost below 20: a ray is done after two or three node steps, so a wave mostly refills)
-    // prefers fewer: the Cornell box loses 11 % at 96
-    const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? (ctx->accel_stats.sah_cost >= 20.0f ? 64u : 48u) : 40u);
+    // prefers fewer: the Cornell box loses 11 % at 96 and gains 8 ... 12 % from 48 to 32 (24 and 32 alike, 16 loses 8 %).
+    // Deep scenes without suspension are flat from 24 to 64 in long runs at 1920x1080 (Bistro-class +3 % at 32), but a run of
+    // twenty frames and 3840x2160 lose 3 % at 32: 64 stays
+    const uint32_t ext_waves_per_cu = waves_override ? waves_override : (chains >= 16 ? (ctx->accel_stats.sah_cost >= 20.0f ? 64u : 32u) : 40u);
     uint32_t max_blocks = (uint32_t)ctx->num_cus * 8u;
     uint32_t ext_blocks = chain_grid(EXT_BLOCK, (uint32_t)ctx->num_cus * ext_waves_per_cu, nframes);
     static const uint32_t shade_override = getenv("PT_SHADE_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PT_SHADE_WAVES_PER_CU")) : 0u;
