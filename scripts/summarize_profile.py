@@ -48,7 +48,10 @@ for r in res:
 try:
     bench = [json.loads(l) for l in open(os.path.join(src, "trace.log")) if l.startswith('{"metric"')][-1]
     rl = bench["roofline"]
-    prod = agg.get("ptd::k_extend<false, true>")
+    # the production traversal kernel: k_extend<false, false> in batches that do not suspend rays (four frames or more),
+    # k_extend<false, true> in those that do; whichever ran more often in this profile
+    prod_name = max(("ptd::k_extend<false, false>", "ptd::k_extend<false, true>"), key=lambda k: agg.get(k, (0, 0.0))[0])
+    prod = agg.get(prod_name)
     # the same launches bench.py timed: the plain traversal launches just before the counting pass (k_extend<true, ...>) begins
     window_avg = float("nan")
     try:
@@ -62,7 +65,7 @@ try:
     except sqlite3.Error:
         pass
     lines += ["", "bench.py inside this run: value %.1f %s, roofline.avg_launch_ms %.4f (HIP events on the launch's stream, %d launches of the timing window), "
-              "concurrency %.2f; rocprofv3's average duration of those same launches: %.4f ms (of k_extend<false, true> over the whole run: %.4f ms)"
+              "concurrency %.2f; rocprofv3's average duration of those same launches: %.4f ms (of the production traversal kernel over the whole run: %.4f ms)"
               % (bench["value"], bench["unit"], rl["avg_launch_ms"], rl["launches"], rl["concurrency"], window_avg, prod[1] / prod[0] * 1e-3 if prod else float("nan")),
               "", "Kernel tracing costs throughput here: the profiler's per-dispatch bookkeeping keeps fewer launches in flight at a time "
               "(concurrency above, against roughly twice as many without the profiler), so each launch shares the chip with fewer others and is shorter "
@@ -80,9 +83,10 @@ for path in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_results.db"))):
         if "ptd::" not in kname:
             continue
         pmc.setdefault(short(kname), {})[cname] = {"dispatches": n, "avg": avg, "sum": total}
-# the production traversal kernel: k_extend<false, true> (rounds that may defer rays); the last round of a frame
-# runs k_extend<false, false> on a nearly empty queue
-ext = pmc.get("ptd::k_extend<false, true>", {})
+# the production traversal kernel: k_extend<false, false> in batches that do not suspend rays, k_extend<false, true> in those
+# that do (and then <false, false> only for the last round); whichever has more dispatches in this profile
+ext = max((pmc.get("ptd::k_extend<false, false>", {}), pmc.get("ptd::k_extend<false, true>", {})),
+          key=lambda v: next(iter(v.values()))["dispatches"] if v else 0)
 summary = {"source": "rocprofv3 --pmc, one pass per counter group, bench.py --steps 16 --warmup 2 --cpu-seconds 0 --others 0", "per_kernel": pmc}
 if "FETCH_SIZE" in ext:
     raw_kb = ext["FETCH_SIZE"]["avg"]
