@@ -275,7 +275,6 @@ int pt_create(int device_ordinal, pt_ctx** out)
         if (c >= 1 && c <= PT_MAX_CHAINS && PT_SHARDS % c == 0) ctx->chains = c;
     }
     if (es == hipSuccess) es = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
-    if (const char* e = getenv("PT_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (const char* e = getenv("PT_BATCH")) { int v = atoi(e); ctx->batch = v < 1 ? 1u : (v > PT_MAX_BATCH ? (uint32_t)PT_MAX_BATCH : (uint32_t)v); }
     if (es == hipSuccess) es = hipMalloc((void**)&ctx->d_views, sizeof(FrameView) * PT_MAX_BATCH * PT_MAX_CHAINS);
     if (es == hipSuccess) es = hipHostMalloc((void**)&ctx->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent);
@@ -313,8 +312,6 @@ void pt_destroy(pt_ctx* ctx)
         if (slot.h_counts) (void)hipHostFree(slot.h_counts);
     }
     if (ctx->prof_ref) (void)hipEventDestroy(ctx->prof_ref);
-    for (uint32_t c = 0; c < PT_MAX_CHAINS; c++)
-        if (ctx->graph_exec[c]) (void)hipGraphExecDestroy(ctx->graph_exec[c]);
     for (uint32_t c = 1; c < PT_MAX_CHAINS; c++) {
         if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
         if (ctx->chain_stream[c]) (void)hipStreamDestroy(ctx->chain_stream[c]);

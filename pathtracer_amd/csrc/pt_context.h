@@ -36,9 +36,6 @@ struct pt_ctx {
     hipEvent_t chain_done[PT_MAX_CHAINS] = {};
     hipEvent_t fork_event = nullptr;
     hipEvent_t wait_event = nullptr;   // pt_wait_stream: marks the caller's stream
-    bool use_graph = false;                          // PT_GRAPH=1 in the environment at pt_create
-    hipGraphExec_t graph_exec[PT_MAX_CHAINS] = {};   // a chain's batch as a captured graph, and the launch arguments it holds
-    std::string graph_key[PT_MAX_CHAINS];
     bool main_dirty = true;      // the main stream got work the other chains have not yet been ordered after
     bool join_pending = false;   // the other chains got work the main stream has not yet been ordered after
 

@@ -34,7 +34,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <string>
 
 namespace ptd {
 
@@ -569,11 +568,6 @@ int launch_trace(pt_ctx* ctx)
     ctx->main_dirty = false;
 
     uint32_t tiles = ((P.width + 7u) >> 3) * ((P.height + 7u) >> 3);
-    // PT_GRAPH=1 when the context was created: a chain's batch (everything but the camera upload, whose argument changes
-    // with every batch) is captured once as a HIP graph and replayed while the launch arguments stay the same.  One graph
-    // launch per chain and batch instead of 25 kernel launches: the host's share per frame falls; the GPU side does not
-    // change measurably (the launches of a chain were never what the chip waited for), so it is off by default
-    const bool graph_on = ctx->use_graph;
     for (uint32_t c = 0; c < chains; c++) {
         hipStream_t st = ctx->chain_stream[c];
         size_t ev = 0;
@@ -581,111 +575,75 @@ int launch_trace(pt_ctx* ctx)
         uint32_t* counts = ctx->d_counts + c * chain_words;
         uint32_t* cursors = counts + (size_t)(layout_rounds + 1) * spc;
         uint32_t* deferred = cursors + (size_t)(layout_rounds + 1) * spc;
+        PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
+        Queues q;
+        q.hits = ctx->d_hits;
+        q.hit_det = ctx->d_hit_det;
+        q.stC = ctx->d_stC;
+        q.counts = counts;
+        q.shard0 = c * spc; q.nshards = spc;
+        q.shard_cap = ctx->shard_cap;
+        q.primary = ctx->d_primary;
+        q.image = ctx->d_image; q.accum = ctx->d_accum;
+        q.partial = ctx->d_partial;
+        q.views = ctx->d_views + c * PT_MAX_BATCH;
         k_set_views<<<1, 64, 0, st>>>(views, ctx->d_views + c * PT_MAX_BATCH);
-        // dry: only collects the launch arguments into `key`
-        auto issue = [&](bool dry, std::string* key) -> int {
-            auto feed = [&](const void* ptr, size_t n) { if (key) key->append(reinterpret_cast<const char*>(ptr), n); };
-            if (!dry) PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
-            Queues q;
-            memset(&q, 0, sizeof(q));
-            q.hits = ctx->d_hits;
-            q.hit_det = ctx->d_hit_det;
-            q.stC = ctx->d_stC;
-            q.counts = counts;
-            q.shard0 = c * spc; q.nshards = spc;
-            q.shard_cap = ctx->shard_cap;
-            q.primary = ctx->d_primary;
-            q.image = ctx->d_image; q.accum = ctx->d_accum;
-            q.partial = ctx->d_partial;
-            q.views = ctx->d_views + c * PT_MAX_BATCH;
-            uint2* spill = ctx->d_spill + (size_t)c * ext_blocks_max * (ctx->stack_entries * 64);
-            feed(&P, sizeof(P)); feed(&sv, sizeof(sv)); feed(&chain_words, sizeof(chain_words)); feed(&rounds, sizeof(rounds));
-            feed(&ext_blocks, sizeof(ext_blocks)); feed(&sh_blocks, sizeof(sh_blocks)); feed(&ctx->precision, sizeof(ctx->precision));
-            feed(&ctx->d_total_rays, sizeof(void*));
+        uint2* spill = ctx->d_spill + (size_t)c * ext_blocks_max * (ctx->stack_entries * 64);
 
-            if (!dry) PT_HIP(ctx, mark());
-            {
-                q.rayO_in = q.rayO_out = ctx->d_rayO[0];
-                q.rayD_in = q.rayD_out = ctx->d_rayD[0];
-                q.stA_in = q.stA_out = ctx->d_stA[0];
-                q.stB_in = q.stB_out = ctx->d_stB[0];
-                uint32_t blocks = ((tiles / chains + spc) * nframes * 64u + 255u) / 256u;
-                if (blocks > max_blocks) blocks = max_blocks;
-                feed(&q, sizeof(q)); feed(&blocks, sizeof(blocks));
-                if (!dry) k_raygen<<<blocks, 256, 0, st>>>(P, q);
-            }
-            if (!dry) PT_HIP(ctx, mark());
-            for (uint32_t r = 0; r < rounds; r++) {
-                int in = (int)(r & 1u), out = in ^ 1;
-                ExtendArgs ea;
-                memset(&ea, 0, sizeof(ea));
-                ea.tmin = P.tmin; ea.tmax = P.tmax;
-                ea.counts = counts + r * spc; ea.cursors = cursors + r * spc;
-                ea.next_counts = (defer && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
-                ea.max_lag = defer;
-                ea.susp_cap = susp_cap;
-                ea.susp_words = susp_words;
-                ea.stack_entries = ctx->stack_entries;
-                ea.susp_in = ctx->d_suspend + ((size_t)(c * 2 + in) * spc) * susp_cap * susp_words;
-                ea.susp_out = ctx->d_suspend + ((size_t)(c * 2 + out) * spc) * susp_cap * susp_words;
-                ea.deferred = deferred;
-                ea.shard0 = q.shard0; ea.nshards = spc; ea.shard_cap = ctx->shard_cap;
-                ea.rayO = ctx->d_rayO[in]; ea.rayD = ctx->d_rayD[in];
-                ea.next_rayO = ctx->d_rayO[out]; ea.next_rayD = ctx->d_rayD[out];
-                ea.stA = ctx->d_stA[in]; ea.stB = ctx->d_stB[in];
-                ea.next_stA = ctx->d_stA[out]; ea.next_stB = ctx->d_stB[out];
-                ea.hits = ctx->d_hits;
-                ea.hit_det = ctx->d_hit_det;
-                ea.spill = spill;
-                ea.iter_cap = ctx->iter_cap;
-                ea.fault = ctx->d_fault;
-                feed(&ea, sizeof(ea));
-                if (!dry) {
-                    unsigned long long* wt = wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr;
-                    if (counting && ea.next_counts) k_extend<true, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
-                    else if (counting) k_extend<true, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
-                    else if (ea.next_counts) k_extend<false, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, nullptr, nullptr);
-                    else k_extend<false, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, nullptr, nullptr);
-                    PT_HIP(ctx, mark());
-                }
-                q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
-                q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
-                q.stA_in = ctx->d_stA[in]; q.stB_in = ctx->d_stB[in];
-                q.stA_out = ctx->d_stA[out]; q.stB_out = ctx->d_stB[out];
-                if (!dry) {
-                    if (ctx->precision == PT_PRECISION_FAST) fast::k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
-                    else k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
-                    PT_HIP(ctx, mark());
-                }
-            }
-            if (!dry) {
-                uint32_t blocks = ((tiles / chains + spc) * 64u + 255u) / 256u;
-                if (blocks > max_blocks) blocks = max_blocks;
-                k_accumulate<<<blocks, 256, 0, st>>>(P, q);
-                k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, deferred, ctx->d_total_rays);
-            }
-            return PT_OK;
-        };
-        if (graph_on && !prof) {
-            std::string key;
-            (void)issue(true, &key);
-            if (!ctx->graph_exec[c] || ctx->graph_key[c] != key) {
-                if (ctx->graph_exec[c]) { (void)hipGraphExecDestroy(ctx->graph_exec[c]); ctx->graph_exec[c] = nullptr; }
-                hipGraph_t g = nullptr;
-                PT_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-                int rc = issue(false, nullptr);
-                hipError_t ce = hipStreamEndCapture(st, &g);
-                if (rc) return rc;
-                PT_HIP(ctx, ce);
-                PT_HIP(ctx, hipGraphInstantiate(&ctx->graph_exec[c], g, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(g);
-                ctx->graph_key[c] = key;
-            }
-            PT_HIP(ctx, hipGraphLaunch(ctx->graph_exec[c], st));
-        } else {
-            int rc = issue(false, nullptr);
-            if (rc) return rc;
+        PT_HIP(ctx, mark());
+        {
+            q.rayO_in = q.rayO_out = ctx->d_rayO[0];
+            q.rayD_in = q.rayD_out = ctx->d_rayD[0];
+            q.stA_in = q.stA_out = ctx->d_stA[0];
+            q.stB_in = q.stB_out = ctx->d_stB[0];
+            uint32_t blocks = ((tiles / chains + spc) * nframes * 64u + 255u) / 256u;
+            if (blocks > max_blocks) blocks = max_blocks;
+            k_raygen<<<blocks, 256, 0, st>>>(P, q);
         }
+        PT_HIP(ctx, mark());
+        for (uint32_t r = 0; r < rounds; r++) {
+            int in = (int)(r & 1u), out = in ^ 1;
+            ExtendArgs ea;
+            ea.tmin = P.tmin; ea.tmax = P.tmax;
+            ea.counts = counts + r * spc; ea.cursors = cursors + r * spc;
+            ea.next_counts = (defer && r + 1 < rounds) ? counts + (r + 1) * spc : nullptr;
+            ea.max_lag = defer;
+            ea.susp_cap = susp_cap;
+            ea.susp_words = susp_words;
+            ea.stack_entries = ctx->stack_entries;
+            ea.susp_in = ctx->d_suspend + ((size_t)(c * 2 + in) * spc) * susp_cap * susp_words;
+            ea.susp_out = ctx->d_suspend + ((size_t)(c * 2 + out) * spc) * susp_cap * susp_words;
+            ea.deferred = deferred;
+            ea.shard0 = q.shard0; ea.nshards = spc; ea.shard_cap = ctx->shard_cap;
+            ea.rayO = ctx->d_rayO[in]; ea.rayD = ctx->d_rayD[in];
+            ea.next_rayO = ctx->d_rayO[out]; ea.next_rayD = ctx->d_rayD[out];
+            ea.stA = ctx->d_stA[in]; ea.stB = ctx->d_stB[in];
+            ea.next_stA = ctx->d_stA[out]; ea.next_stB = ctx->d_stB[out];
+            ea.hits = ctx->d_hits;
+            ea.hit_det = ctx->d_hit_det;
+            ea.spill = spill;
+            ea.iter_cap = ctx->iter_cap;
+            ea.fault = ctx->d_fault;
+            unsigned long long* wt = wave_trace ? ctx->d_wave_trace + ((size_t)c * rounds + r) * ext_blocks * 4 : nullptr;
+            if (counting && ea.next_counts) k_extend<true, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
+            else if (counting) k_extend<true, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, ctx->d_stats, wt);
+            else if (ea.next_counts) k_extend<false, true><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, nullptr, nullptr);
+            else k_extend<false, false><<<ext_blocks, EXT_BLOCK, 0, st>>>(sv, ea, nullptr, nullptr);
+            PT_HIP(ctx, mark());
+            q.rayO_in = ctx->d_rayO[in]; q.rayD_in = ctx->d_rayD[in];
+            q.rayO_out = ctx->d_rayO[out]; q.rayD_out = ctx->d_rayD[out];
+            q.stA_in = ctx->d_stA[in]; q.stB_in = ctx->d_stB[in];
+            q.stA_out = ctx->d_stA[out]; q.stB_out = ctx->d_stB[out];
+            if (ctx->precision == PT_PRECISION_FAST) fast::k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
+            else k_shade<<<sh_blocks, SHADE_BLOCK, 0, st>>>(sv, P, q, r);
+            PT_HIP(ctx, mark());
+        }
+        {
+            uint32_t blocks = ((tiles / chains + spc) * 64u + 255u) / 256u;
+            if (blocks > max_blocks) blocks = max_blocks;
+            k_accumulate<<<blocks, 256, 0, st>>>(P, q);
+        }
+        k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, deferred, ctx->d_total_rays);
         if (prof) PT_HIP(ctx, hipMemcpyAsync(slot->h_counts + c * chain_words, counts, chain_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, mark());
     }

@@ -427,41 +427,6 @@ def test_image_does_not_depend_on_ray_suspension(cornell, cameras, monkeypatch, 
         b.close()
 
 
-def test_image_does_not_depend_on_graph_replay(cornell, cameras, monkeypatch):
-    """PT_GRAPH=1 at pt_create: every chain's batch is captured once as a HIP graph and replayed while the launch arguments
-    stay the same; the camera of each batch is uploaded outside the graph.  Twenty frames with the camera moving from frame
-    to frame (so that replays run with new cameras), then a change of the parameters and of the image size (new captures):
-    same bits as the oracle tracing the frames one by one."""
-    from pathtracer_amd.backend import Backend
-    monkeypatch.setenv("PT_GRAPH", "1")
-    b = Backend(0)
-    try:
-        b.scene_upload(cornell)
-        b.build_accel()
-        o = oracle_lib.Oracle(cornell)
-        for (W, H), spp, bounces, nframes in (((160, 96), 1, 5, 20), ((160, 96), 2, 3, 5), ((72, 40), 1, 4, 9)):
-            b.resize(W, H)
-            o.resize(W, H)
-            p = Params.reference(spp_per_frame=spp, max_bounces=bounces)
-            b.set_params(p)
-            o.set_params(p)
-            r0, q0 = b.ray_count(), o.ray_count()
-            for f in range(1, nframes + 1):
-                cam = np.array(cameras["512x512"], np.float32).reshape(5, 4, 4).copy()
-                cam[3, 3, 0] += 0.004 * f
-                cam = cam.reshape(-1)
-                b.set_camera(cam)
-                o.set_camera(cam)
-                b.trace(f)
-                o.trace(f)
-            assert b.ray_count() - r0 == o.ray_count() - q0
-            assert np.array_equal(b.read_primary_ids(), o.read_primary_ids())
-            assert np.array_equal(bits(b.read_accum()), bits(o.read_accum()))
-            assert np.array_equal(bits(b.read_image()), bits(o.read_image()))
-    finally:
-        b.close()
-
-
 def test_iteration_bound_of_the_traversal_is_reported(cornell, cameras, monkeypatch):
     """A traversal wave leaves its loop after a fixed number of iterations whatever the data (2^24 by default, which no
     well-formed hierarchy reaches).  With the bound forced down to 3 (PT_ITER_CAP) every wave reaches it: the waves still
