@@ -608,9 +608,31 @@ def test_long_progressive_run_keeps_its_state(backend):
     o.close()
 
 
+@pytest.mark.parametrize("batch", [1, 2, 8])
+def test_suspension_follows_the_batch_size(backend, batch):
+    """Unless PT_DEFER forces it, a batch of one or two frames over a deep hierarchy (surface-area cost >= 20) suspends the last
+    rays of its traversal launches and takes two more rounds, larger batches do not.  Seven frames issued back to back with
+    1, 2 or 8 frames per batch, then one more frame after a flush (a batch of one following whatever came before on the same
+    chains and counter blocks): same bits as the oracle, whichever kernel variants ran."""
+    sc = procedural.sponza_class(detail=0.2)
+    W, H = 240, 135
+    try:
+        backend.set_batch(batch)
+        o, rays = render_pair(backend, sc, procedural.sponza_camera(W, H), W, H, (1, 2, 3, 4, 5, 6, 7), spp_per_frame=1, max_bounces=6)
+        assert backend.accel.sah_cost >= 20.0           # the rule applies to this scene
+        assert_same_frame(backend, o, rays)
+        r0 = backend.ray_count()
+        backend.trace(8)
+        o.trace(8)
+        assert np.array_equal(bits(backend.read_accum()), bits(o.read_accum()))
+        assert rays + backend.ray_count() - r0 == o.ray_count()
+    finally:
+        backend.set_batch(8)
+
+
 def test_large_scene(backend):
     """The Bistro-class street: 2.97 M triangles, an 11-level hierarchy that outgrows every cache, long grazing rays
-    (the longest traversals suspend and spill).  Ray count, primary ids and every pixel's bits equal the oracle's."""
+    (the longest traversals spill their stacks).  Ray count, primary ids and every pixel's bits equal the oracle's."""
     sc = procedural.bistro_class()
     W, H = 320, 180
     o, rays = render_pair(backend, sc, procedural.bistro_camera(W, H), W, H, (1, 2, 3), spp_per_frame=1, max_bounces=8)
