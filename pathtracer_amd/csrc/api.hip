@@ -112,6 +112,22 @@ int collect_slot(pt_ctx* ctx, pt_prof_slot& slot)
     const uint32_t R = slot.rounds, C = slot.chains, spc = PT_SHARDS / C;
     const size_t chain_words = pt_chain_words(slot.layout_rounds, spc);
     for (uint32_t c = 0; c < C; c++) PT_HIP(ctx, hipEventSynchronize(slot.ev[c][2 + 2 * R]));
+    // PT_SPAN_DUMP=<file>: every launch of the profiled frames as a line "chain kind round start_ms end_ms" (kind r = ray
+    // generation, e = traversal, s = shading, a = accumulation; times since the window's reference event), appended
+    static const char* span_path = getenv("PT_SPAN_DUMP");
+    FILE* span_file = span_path ? fopen(span_path, "a") : nullptr;
+    auto span = [&](uint32_t c, char kind, uint32_t r, hipEvent_t a, hipEvent_t b) {
+        float t0 = 0.0f, dt = 0.0f;
+        if (span_file && hipEventElapsedTime(&t0, ctx->prof_ref, a) == hipSuccess && hipEventElapsedTime(&dt, a, b) == hipSuccess)
+            fprintf(span_file, "%u %c %u %.4f %.4f\n", c, kind, r, t0, t0 + dt);
+    };
+    for (uint32_t c = 0; span_file && c < C; c++) {
+        std::vector<hipEvent_t>& ev = slot.ev[c];
+        span(c, 'r', 0, ev[0], ev[1]);
+        for (uint32_t r = 0; r < R; r++) { span(c, 'e', r, ev[1 + 2 * r], ev[2 + 2 * r]); span(c, 's', r, ev[2 + 2 * r], ev[3 + 2 * r]); }
+        span(c, 'a', 0, ev[1 + 2 * R], ev[2 + 2 * R]);
+    }
+    if (span_file) { fputs("#\n", span_file); fclose(span_file); }
     for (uint32_t c = 0; c < C; c++) {
         std::vector<hipEvent_t>& ev = slot.ev[c];
         float ms = 0.0f;
