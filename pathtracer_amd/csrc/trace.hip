@@ -611,8 +611,9 @@ int launch_trace(pt_ctx* ctx)
             ea.susp_cap = susp_cap;
             ea.susp_words = susp_words;
             ea.stack_entries = ctx->stack_entries;
-            ea.susp_in = ctx->d_suspend + ((size_t)(c * 2 + in) * spc) * susp_cap * susp_words;
-            ea.susp_out = ctx->d_suspend + ((size_t)(c * 2 + out) * spc) * susp_cap * susp_words;
+            // records only exist once a batch has suspended rays; a launch that does not suspend never looks at them
+            ea.susp_in = defer ? ctx->d_suspend + ((size_t)(c * 2 + in) * spc) * susp_cap * susp_words : nullptr;
+            ea.susp_out = defer ? ctx->d_suspend + ((size_t)(c * 2 + out) * spc) * susp_cap * susp_words : nullptr;
             ea.deferred = deferred;
             ea.shard0 = q.shard0; ea.nshards = spc; ea.shard_cap = ctx->shard_cap;
             ea.rayO = ctx->d_rayO[in]; ea.rayD = ctx->d_rayD[in];
