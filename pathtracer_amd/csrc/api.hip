@@ -209,8 +209,8 @@ int check_fault(pt_ctx* ctx)
     if (!ctx->h_fault || *(volatile uint32_t*)ctx->h_fault == 0u) return PT_OK;
     *(volatile uint32_t*)ctx->h_fault = 0u;
     return set_error(ctx, PT_ERR_TRAVERSAL, "a traversal wave reached its iteration bound (" + std::to_string(ctx->iter_cap) +
-                     " loop iterations): its rays were reported with the closest hit found so far and the rest of its queue as misses, "
-                     "so the frames and ray queries since the last synchronisation are not valid");
+                     " loop iterations) and left hit records unwritten: "
+                     "the frames and ray queries since the last synchronisation are not valid");
 }
 
 int sync_streams(pt_ctx* ctx)

@@ -408,9 +408,8 @@ PT_DEV void finish_hit(Trav& s)
 // lds_stack points at this lane's column: entry k is lds_stack[k * stride]; ovf points at this lane's
 // column of the wave's global spill area: entry k is ovf[k * 64]; scratch is the wave's PT_SCRATCH_WORDS words of LDS.
 // iter_cap bounds the loop (PT_ITER_CAP_DEFAULT; never reached by a well-formed hierarchy, where a ray takes a few hundred
-// steps at most): a wave that reaches it reports its rays' closest hits so far, reports every ray still in the queue as a
-// miss, so that no hit record is left unwritten, and sets *fault, which the host turns into PT_ERR_TRAVERSAL at its next
-// synchronisation.
+// steps at most): a wave that reaches it leaves, with the hit records of its unfinished and unfetched rays unwritten, and sets
+// *fault, which the host turns into PT_ERR_TRAVERSAL at its next synchronisation.
 #define PT_ITER_CAP_DEFAULT (1u << 24)
 template <bool STATS, bool CUT, class Fetch, class Emit, class Suspend, class ResumeRecord>
 PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict__ tris, uint32_t num_tris, uint32_t n,
@@ -510,24 +509,11 @@ PT_DEV void trace_wave(const Node8* __restrict__ nodes, const TriRec* __restrict
             }
         }
     }
-    if (iter >= iter_cap) {       // wave-uniform: the loop was cut short
-        if (has) { emit(my, s); has = false; }
-        while (!exhausted) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(cursor, 64u);
-            base = __shfl(base, 0);
-            const uint32_t i = base + lane;
-            if (i < n) {
-                v3 o, d;
-                float tmin, tmax;
-                (void)fetch(i, o, d, tmin, tmax);
-                trav_init(s, o, d, tmin, tmax);
-                emit(i, s);
-            }
-            if (base + 64u >= n) exhausted = true;
-        }
-        if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    // the loop was cut short (wave-uniform): only the flag is raised.  Writing the hit records the wave still owes at this point
+    // (its rays' closest hits so far, misses for the rest of the queue) kept ray state alive behind the loop and cost the loop
+    // itself 1 % (2.7 % in the variant that can suspend rays); the records stay as they were, the shading stage takes a
+    // triangle number beyond the table for a miss, and the host declares everything since its last synchronisation invalid
+    if (iter >= iter_cap && lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (STATS && wave_stats) {
         unsigned long long t_end = wall_clock64();
         wave_stats->t_start = t_start;

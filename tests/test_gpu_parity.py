@@ -429,9 +429,9 @@ def test_image_does_not_depend_on_ray_suspension(cornell, cameras, monkeypatch, 
 
 def test_iteration_bound_of_the_traversal_is_reported(cornell, cameras, monkeypatch):
     """A traversal wave leaves its loop after a fixed number of iterations whatever the data (2^24 by default, which no
-    well-formed hierarchy reaches).  With the bound forced down to 3 (PT_ITER_CAP) every wave reaches it: the waves still
-    write every hit record (closest hit so far, misses for rays not yet fetched), and the next synchronising call returns
-    PT_ERR_TRAVERSAL instead of handing out the frame silently.  The context stays usable."""
+    well-formed hierarchy reaches).  With the bound forced down to 3 (PT_ITER_CAP) every wave reaches it and leaves hit records
+    unwritten: the shading stage survives whatever those records hold (a triangle number beyond the table is a miss), and the next
+    synchronising call returns PT_ERR_TRAVERSAL instead of handing out the frame silently.  The context stays usable."""
     from pathtracer_amd.backend import Backend
     monkeypatch.setenv("PT_ITER_CAP", "3")
     b = Backend(0)
