@@ -10,7 +10,7 @@
 //              next queue with one ballot + one atomic per wave
 //   k_accumulate  RayGen.glsl:347-372  adds the finished frames to the accumulation image in frame
 //              order (frame 1 clears it), writes the running mean, NaN -> red
-//   k_finish   adds the batch's queue sizes to the ray counter
+//              and adds the batch's queue sizes to the ray counter
 //
 // Up to PT_MAX_BATCH consecutive frames are traced by the same launches: a path is a (frame slot,
 // pixel) pair, with the slot's own frame index and camera (k_set_views).  A (slot, pixel) owns one
@@ -130,9 +130,12 @@ PT_DEV uint32_t wave_append(bool alive, uint32_t* counter)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-__global__ void k_set_views(FrameViewBatch b, FrameView* dst)
+// start of a chain's batch, one wave: the batch's cameras, and the chain's queue counters back to zero (a launch of its own for
+// either costs the chain a trip through the command processor)
+__global__ void k_set_views(FrameViewBatch b, FrameView* dst, uint32_t* counts, uint32_t words)
 {
     if (threadIdx.x < PT_MAX_BATCH) dst[threadIdx.x] = b.v[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) counts[i] = 0u;
 }
 
 // number of 8x8 tiles of the chain: tile t belongs to shard t % PT_SHARDS
@@ -313,8 +316,15 @@ PT_DEV int wrap_index(int i, int n, uint32_t mode)
 
 // RayGen.glsl:347-372 for every pixel of the chain and every frame of the batch, in frame order: the finished colours
 // wait in q.partial, so that a pixel's frames are added in the order of the pt_trace calls whatever order they finished in
-__global__ void __launch_bounds__(256) k_accumulate(TraceParams P, Queues q)
+__global__ void __launch_bounds__(256) k_accumulate(TraceParams P, Queues q, uint32_t count_entries, const uint32_t* deferred, unsigned long long* total)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // the chain's rays of this batch = sum of all its queue sizes, less the rays queued twice (suspended ones)
+        unsigned long long s = 0;
+        for (uint32_t r = threadIdx.x; r < count_entries; r += 64) s += q.counts[r];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (threadIdx.x == 0) atomicAdd(total, s - *deferred);
+    }
     const uint32_t ctiles = chain_tiles(P, q), npix = P.width * P.height;
     const uint32_t nslots = ctiles * 64u;
     for (uint32_t cs = blockIdx.x * blockDim.x + threadIdx.x; cs < nslots; cs += gridDim.x * blockDim.x) {
@@ -377,15 +387,6 @@ PT_DEV float4 sample_texture(const SceneView& sc, int tex, float u, float v)
 
 #include "pt_shade.inc"      // sample_env, fetch_surface, k_shade: bit-exact arithmetic
 #include "pt_fast.h"         // the same text again as ptd::fast::k_shade with the hardware's approximations
-
-__global__ void k_finish(const uint32_t* counts, uint32_t entries, const uint32_t* deferred, unsigned long long* total)
-{
-    // one wave per chain: rays traced this frame = sum of all its queue sizes, less the rays queued twice
-    unsigned long long s = 0;
-    for (uint32_t r = threadIdx.x; r < entries; r += 64) s += counts[r];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (threadIdx.x == 0) atomicAdd(total, s - *deferred);
-}
 
 __global__ void k_resolve(uint32_t n, const float* __restrict__ accum, float* __restrict__ image)
 {
@@ -575,7 +576,6 @@ int launch_trace(pt_ctx* ctx)
         uint32_t* counts = ctx->d_counts + c * chain_words;
         uint32_t* cursors = counts + (size_t)(layout_rounds + 1) * spc;
         uint32_t* deferred = cursors + (size_t)(layout_rounds + 1) * spc;
-        PT_HIP(ctx, hipMemsetAsync(counts, 0, chain_words * sizeof(uint32_t), st));
         Queues q;
         q.hits = ctx->d_hits;
         q.hit_det = ctx->d_hit_det;
@@ -587,7 +587,7 @@ int launch_trace(pt_ctx* ctx)
         q.image = ctx->d_image; q.accum = ctx->d_accum;
         q.partial = ctx->d_partial;
         q.views = ctx->d_views + c * PT_MAX_BATCH;
-        k_set_views<<<1, 64, 0, st>>>(views, ctx->d_views + c * PT_MAX_BATCH);
+        k_set_views<<<1, 64, 0, st>>>(views, ctx->d_views + c * PT_MAX_BATCH, counts, (uint32_t)chain_words);
         uint2* spill = ctx->d_spill + (size_t)c * ext_blocks_max * (ctx->stack_entries * 64);
 
         PT_HIP(ctx, mark());
@@ -642,9 +642,8 @@ int launch_trace(pt_ctx* ctx)
         {
             uint32_t blocks = ((tiles / chains + spc) * 64u + 255u) / 256u;
             if (blocks > max_blocks) blocks = max_blocks;
-            k_accumulate<<<blocks, 256, 0, st>>>(P, q);
+            k_accumulate<<<blocks, 256, 0, st>>>(P, q, rounds * spc, deferred, ctx->d_total_rays);
         }
-        k_finish<<<1, 64, 0, st>>>(counts, rounds * spc, deferred, ctx->d_total_rays);
         if (prof) PT_HIP(ctx, hipMemcpyAsync(slot->h_counts + c * chain_words, counts, chain_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, mark());
     }
